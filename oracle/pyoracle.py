@@ -1,0 +1,200 @@
+"""ctypes drivers for the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Two back ends with the same call signatures:
+
+* ``port``  -- oracle/liboracle_port.so, the plain-C restatement (oracle_swd.c, oracle_rf.c).
+* ``ref``   -- oracle/_ref/lib{surfdisp96,rfmini}_ref.so, the reference's own native sources
+               compiled by oracle/Makefile (`make ref`) in the development container.  Used to pin
+               the restatement, to generate tests/golden/*.npz, and -- when present -- as the
+               ``cpu_baseline.kind == "reference"`` leg of bench.py.
+
+Nothing under bayhunter_amd/ may import this module (checked by tests/test_layout.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NL, NP = 100, 60  # surfdisp96.f:60-62
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def build_port():
+    """Compile the C restatement (and, if /root/reference exists, oracle/_ref)."""
+    subprocess.run(["make", "-s", "-C", _HERE, "port"], check=True)
+    if os.path.isdir("/root/reference/src/extensions"):
+        subprocess.run(["make", "-s", "-C", _HERE, "ref"], check=True)
+
+
+_port = None
+_ref_swd = None
+_ref_rf = None
+
+
+def port_lib():
+    global _port
+    if _port is None:
+        path = os.path.join(_HERE, "liboracle_port.so")
+        if not os.path.exists(path):
+            build_port()
+        lib = C.CDLL(path)
+        lib.bho_surfdisp96.restype = C.c_int
+        lib.bho_surfdisp96.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, _dp, _dp, C.POINTER(C.c_long)]
+        lib.bho_surfdisp96_batch.restype = None
+        lib.bho_surfdisp96_batch.argtypes = [C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip,
+                                             C.POINTER(C.c_long), C.c_int]
+        lib.bho_synrf.restype = C.c_int
+        lib.bho_synrf.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_int, C.c_int,
+                                  _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        lib.bho_rf_batch.restype = None
+        lib.bho_rf_batch.argtypes = [C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, C.c_double,
+                                     C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
+                                     C.c_int, C.c_int, _dp, C.c_int]
+        _port = lib
+    return _port
+
+
+def have_ref():
+    return (os.path.exists(os.path.join(_HERE, "_ref", "libsurfdisp96_ref.so"))
+            and os.path.exists(os.path.join(_HERE, "_ref", "librfmini_ref.so")))
+
+
+def ref_swd_lib():
+    global _ref_swd
+    if _ref_swd is None:
+        lib = C.CDLL(os.path.join(_HERE, "_ref", "libsurfdisp96_ref.so"))
+        lib.surfdisp96_.restype = None
+        lib.surfdisp96_.argtypes = [_fp, _fp, _fp, _fp, _ip, _ip, _ip, _ip, _ip, _ip, _dp, _dp, _ip]
+        _ref_swd = lib
+    return _ref_swd
+
+
+def ref_rf_lib():
+    global _ref_rf
+    if _ref_rf is None:
+        lib = C.CDLL(os.path.join(_HERE, "_ref", "librfmini_ref.so"))
+        lib.synrf_cwrap.restype = C.c_int
+        lib.synrf_cwrap.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_int, C.c_int,
+                                    _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _ref_rf = lib
+    return _ref_rf
+
+
+# --------------------------------------------------------------------------- SWD, one model
+def _pad32(x):
+    out = np.zeros(NL, dtype=np.float32)
+    out[:len(x)] = np.asarray(x, dtype=np.float64).astype(np.float32)
+    return out
+
+
+def swd(h, vp, vs, rho, periods, iwave, igr, mode=1, flsph=0, backend="port", count=False):
+    """One surfdisp96 call, argument meaning as surf96_modsw.py:116.  Returns (cg[kmax], err)."""
+    n, kmax = len(h), len(periods)
+    assert n <= NL and kmax <= NP
+    th, a, b, r = _pad32(h), _pad32(vp), _pad32(vs), _pad32(rho)
+    t = np.zeros(NP)
+    t[:kmax] = periods
+    cg = np.zeros(NP)
+    if backend == "port":
+        nc = C.c_long(0)
+        err = port_lib().bho_surfdisp96(_p(th, _fp), _p(a, _fp), _p(b, _fp), _p(r, _fp), n, flsph,
+                                        iwave, mode, igr, kmax, _p(t, _dp), _p(cg, _dp),
+                                        C.byref(nc))
+        if count:
+            return cg[:kmax].copy(), err, nc.value
+    elif backend == "ref":
+        ints = [C.c_int(v) for v in (n, flsph, iwave, mode, igr, kmax)]
+        e = C.c_int(0)
+        ref_swd_lib().surfdisp96_(_p(th, _fp), _p(a, _fp), _p(b, _fp), _p(r, _fp),
+                                  *[C.byref(i) for i in ints], _p(t, _dp), _p(cg, _dp), C.byref(e))
+        err = e.value
+    else:
+        raise ValueError(backend)
+    return cg[:kmax].copy(), err
+
+
+def swd_batch(H, VP, VS, RHO, nlay, periods, iwave, igr, mode=1, flsph=0, backend="port",
+              nthreads=1):
+    """Batched SWD on fp64 [B, Lmax] arrays.  Returns (out[B,kmax], err[B], n_dltar_total)."""
+    H, VP, VS, RHO = (np.ascontiguousarray(x, dtype=np.float64) for x in (H, VP, VS, RHO))
+    B, Lmax = H.shape
+    nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+    periods = np.ascontiguousarray(periods, dtype=np.float64)
+    kmax = periods.size
+    out = np.zeros((B, kmax))
+    err = np.zeros(B, dtype=np.int32)
+    if backend == "port":
+        nc = C.c_long(0)
+        port_lib().bho_surfdisp96_batch(B, Lmax, _p(nlay, _ip), _p(H, _dp), _p(VP, _dp),
+                                        _p(VS, _dp), _p(RHO, _dp), flsph, iwave, mode, igr, kmax,
+                                        _p(periods, _dp), _p(out, _dp), _p(err, _ip),
+                                        C.byref(nc), nthreads)
+        return out, err, nc.value
+    for b in range(B):
+        n = int(nlay[b])
+        out[b], err[b] = swd(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], periods, iwave, igr,
+                             mode, flsph, backend="ref")
+    return out, err, None
+
+
+# --------------------------------------------------------------------------- RF, one model
+def synrf(z, vp, vs, rh, qp, qs, p, a, nsamp, fsamp, tshift, nsv, sigma, waveno, backend="port"):
+    """One synrf_cwrap call (rfmini.pyx:74-114).  Returns (fz, fr, rf), each fp64[nsamp]."""
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (z, vp, vs, rh, qp, qs)]
+    nlay = arrs[0].size
+    nsamp = int(nsamp)
+    fz, fr, rf = np.zeros(nsamp), np.zeros(nsamp), np.zeros(nsamp)
+    fn = port_lib().bho_synrf if backend == "port" else ref_rf_lib().synrf_cwrap
+    fn(nsamp, fsamp, tshift, p, a, nsv, sigma, waveno, nlay, *[_p(x, _dp) for x in arrs],
+       _p(fz, _dp), _p(fr, _dp), _p(rf, _dp))
+    return fz, fr, rf
+
+
+def rf_model(h, vp, vs, rho, p=6.4, gauss=1.0, nsamp=512, fsamp=5.0, tshift=5.0, nsv=None,
+             waveno=0, nout=None, backend="port"):
+    """RFminiModRF.compute_rf for one model (rfmini_modrf.py:99-142): returns rf[:nout]."""
+    h, vp, vs, rho = (np.asarray(x, dtype=np.float64) for x in (h, vp, vs, rho))
+    qp = np.ones(h.size) * 500.
+    qs = np.ones(h.size) * 225.
+    z = np.cumsum(h)
+    z = np.concatenate(([0], z[:-1]))
+    nsvp, nsvs = float(vp[0]), float(vs[0])
+    vpvs = nsvp / nsvs
+    poisson = (2 - vpvs**2) / (2 - 2 * vpvs**2)
+    if nsv is None:
+        nsv = nsvs
+    _, _, rf = synrf(z, vp, vs, rho, qp, qs, p, gauss, nsamp, fsamp, tshift, nsv, poisson, waveno,
+                     backend=backend)
+    return rf[:nout] if nout else rf
+
+
+def rf_batch(H, VP, VS, RHO, nlay, p=6.4, gauss=1.0, nsamp=512, fsamp=5.0, tshift=5.0, nsv=None,
+             waveno=0, nout=201, backend="port", nthreads=1):
+    H, VP, VS, RHO = (np.ascontiguousarray(x, dtype=np.float64) for x in (H, VP, VS, RHO))
+    B, Lmax = H.shape
+    nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+    out = np.zeros((B, nout))
+    if backend == "port":
+        port_lib().bho_rf_batch(B, Lmax, _p(nlay, _ip), _p(H, _dp), _p(VP, _dp), _p(VS, _dp),
+                                _p(RHO, _dp), p, gauss, int(nsamp), fsamp, tshift,
+                                -1.0 if nsv is None else float(nsv), waveno, nout, _p(out, _dp),
+                                nthreads)
+        return out
+    for b in range(B):
+        n = int(nlay[b])
+        out[b] = rf_model(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], p, gauss, nsamp, fsamp,
+                          tshift, nsv, waveno, nout, backend="ref")
+    return out
