@@ -1,0 +1,114 @@
+"""ctypes binding of libbayhunter_amd.so (include/bayhunter_amd.h).
+
+There is no CPU fallback: if the HIP library is missing, or no gfx950 device is usable, every
+compute entry point raises.  `build()` compiles the library in-tree with hipcc (cross-compiles
+without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
+SOURCES = ["kernels.hip", "capi.hip"]
+HEADERS = ["bh_common.h", "swd_core.h", "rf_core.h", "rf_host.h", "kernels.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+
+BH_OK, BH_ERR_ARG, BH_ERR_HIP, BH_ERR_NO_DEVICE, BH_ERR_WORKSPACE = 0, 1, 2, 3, 4
+MAX_LAYERS, MAX_PERIODS, MAX_TARGETS = 100, 60, 16
+
+
+class SwdTarget(C.Structure):
+    """struct bh_swd_target"""
+    _fields_ = [("iwave", C.c_int), ("igr", C.c_int), ("mode", C.c_int), ("iflsph", C.c_int),
+                ("nper", C.c_int), ("per_off", C.c_int), ("out_off", C.c_int), ("_pad", C.c_int)]
+
+
+class RfParams(C.Structure):
+    """struct bh_rf_params"""
+    _fields_ = [("p", C.c_double), ("gauss", C.c_double), ("fsamp", C.c_double),
+                ("tshift", C.c_double), ("nsv", C.c_double), ("nsamp", C.c_int),
+                ("waveno", C.c_int), ("nout", C.c_int), ("out_off", C.c_int)]
+
+
+class BayHunterAmdError(RuntimeError):
+    pass
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps.append(os.path.join(_HERE, "..", "include", "bayhunter_amd.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> bayhunter_amd/csrc/libbayhunter_amd.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + SOURCES + ["-o", LIB_PATH]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    return LIB_PATH
+
+
+_vp = C.c_void_p
+_SIGS = {
+    "bh_version": (C.c_char_p, []),
+    "bh_last_error": (C.c_char_p, []),
+    "bh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "bh_set_device": (C.c_int, [C.c_int]),
+    "bh_swd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(SwdTarget)]),
+    "bh_swd_batch": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                               C.POINTER(SwdTarget), _vp, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "bh_rf_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(RfParams)]),
+    "bh_rf_batch": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              C.POINTER(RfParams), _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "bh_surfdisp96": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, _vp, _vp, C.POINTER(C.c_int)]),
+    "bh_synrf": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                           C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bh_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "bh_free": (C.c_int, [_vp]),
+    "bh_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "bh_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "bh_stream_synchronize": (C.c_int, [_vp]),
+}
+EXPORTS = sorted(_SIGS)
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BayHunterAmdError(
+                "%s not found: build it with bayhunter_amd.build() / python -c "
+                "'import __graft_entry__ as g; g.build()'. There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != BH_OK:
+        msg = load().bh_last_error().decode()
+        raise BayHunterAmdError("libbayhunter_amd error %d: %s" % (rc, msg))
+
+
+def device_count():
+    n = C.c_int(0)
+    load().bh_device_count(C.byref(n))
+    return n.value

@@ -1,0 +1,320 @@
+// capi.hip -- the C ABI of libbayhunter_amd.so (include/bayhunter_amd.h).  Host code only.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/bayhunter_amd.h"
+#include "kernels.h"
+#include "rf_host.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail_hip(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return BH_ERR_HIP;
+}
+int fail_arg(const char *what)
+{
+    g_err = what;
+    return BH_ERR_ARG;
+}
+#define BH_HIP(call)                                          \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return fail_hip(e_, #call);     \
+    } while (0)
+
+// HIP is initialised lazily on first use, never at load time: the reference forks one process per
+// chain (mcmcOptimizer.py:248-252) and a HIP context must not be created before that fork.
+int ensure_device()
+{
+    static thread_local int ok = 0;
+    if (ok) return BH_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_err = "no usable HIP device (libbayhunter_amd has no CPU fallback)";
+        return BH_ERR_NO_DEVICE;
+    }
+    ok = 1;
+    return BH_OK;
+}
+
+// FFT twiddle tables, one per (device, nsamp), built on the host like fork.cpp:50-51.
+std::mutex g_tw_mutex;
+std::map<std::pair<int, int>, double *> g_tw;
+
+int get_twiddles(int nsamp, const double **out)
+{
+    int dev = 0;
+    BH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto key = std::make_pair(dev, nsamp);
+    auto it = g_tw.find(key);
+    if (it == g_tw.end()) {
+        std::vector<double> tw(2 * (size_t)nsamp);
+        bh::rf_fill_twiddles(tw.data(), nsamp);
+        double *d = nullptr;
+        BH_HIP(hipMalloc((void **)&d, tw.size() * sizeof(double)));
+        BH_HIP(hipMemcpy(d, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = g_tw.emplace(key, d).first;
+    }
+    *out = it->second;
+    return BH_OK;
+}
+
+int pick_rf_M(int B, int Lmax, int nsamp)
+{
+    // as many models per workgroup as fit ~64 KiB of LDS (two workgroups per CU), at most 8: with
+    // nfreq = 2^k+1 tasks per model the partial last round costs 1/(4M+1) of the issue slots
+    size_t per = bh::rf_lds_bytes(Lmax, nsamp, 1);
+    int M = (int)((64 * 1024) / per);
+    if (M > 8) M = 8;
+    if (M < 1) M = 1;
+    if (M > B) M = B;
+    return M;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *bh_version(void) { return "bayhunter_amd 0.1 (gfx950)"; }
+const char *bh_last_error(void) { return g_err.c_str(); }
+
+int bh_device_count(int *count)
+{
+    if (!count) return fail_arg("count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return BH_OK;
+}
+
+int bh_set_device(int device)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    BH_HIP(hipSetDevice(device));
+    return BH_OK;
+}
+
+size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets)
+{
+    if (!targets || B <= 0) return 0;
+    for (int t = 0; t < ntargets; t++)
+        if (targets[t].mode > 1) return (size_t)ntargets * 2 * bh::BH_NP * (size_t)B * sizeof(double);
+    return 0;
+}
+
+int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
+                 const double *vs, const double *rho, int ntargets, const bh_swd_target *targets,
+                 const double *periods, double *out, int out_stride, int *err, void *workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
+    if (ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("ntargets out of range");
+    if (!nlay || !h || !vp || !vs || !rho || !targets || !periods || !out || !err)
+        return fail_arg("NULL pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return BH_OK;
+    bh::SwdArgs A;
+    std::memset(&A, 0, sizeof(A));
+    for (int t = 0; t < ntargets; t++) {
+        const bh_swd_target &s = targets[t];
+        if (s.iwave != 1 && s.iwave != 2) return fail_arg("iwave must be 1 (Love) or 2 (Rayleigh)");
+        if (s.nper < 0 || s.nper > BH_MAX_PERIODS) return fail_arg("nper out of range (max 60)");
+        if (s.mode < 1) return fail_arg("mode must be >= 1");
+        if (s.out_off < 0 || s.out_off + s.nper > out_stride) return fail_arg("target does not fit the output row");
+        A.tg[t] = bh::SwdTargetDev{s.iwave, s.igr, s.mode, s.iflsph, s.nper, s.per_off, s.out_off, 0};
+    }
+    size_t need = bh_swd_workspace_bytes(B, ntargets, targets);
+    if (need > 0 && (!workspace || workspace_bytes < need)) {
+        g_err = "workspace too small for mode > 1 (bh_swd_workspace_bytes)";
+        return BH_ERR_WORKSPACE;
+    }
+    A.B = B; A.Lmax = Lmax; A.ntargets = ntargets; A.out_stride = out_stride;
+    A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.periods = periods;
+    A.out = out; A.err = err; A.ws = (double *)workspace;
+    BH_HIP(bh::launch_swd(A, (hipStream_t)stream));
+    return BH_OK;
+}
+
+size_t bh_rf_workspace_bytes(int, int, const bh_rf_params *) { return 0; }
+
+static int rf_launch_common(int B, int Lmax, const int *nlay, const double *h, const double *vp,
+                            const double *vs, const double *rho, const double *qp, const double *qs,
+                            const bh_rf_params *par, double sigma, int depth_input, double *out,
+                            int out_stride, void *stream)
+{
+    if (!par) return fail_arg("par is NULL");
+    if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
+    if (!nlay || !h || !vp || !vs || !rho || !out) return fail_arg("NULL pointer");
+    int n = par->nsamp;
+    if (n < 8 || n > 4096 || (n & (n - 1))) return fail_arg("nsamp must be a power of two in 8..4096");
+    if (par->waveno != 0 && par->waveno != 1) return fail_arg("waveno must be 0 (P) or 1 (SV)");
+    if (par->nout < 1 || par->nout > n) return fail_arg("nout out of range");
+    if (par->out_off < 0 || par->out_off + par->nout > out_stride) return fail_arg("RF does not fit the output row");
+    if (!(par->gauss > 0) || !(par->fsamp > 0)) return fail_arg("gauss and fsamp must be positive");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return BH_OK;
+    bh::RfArgs A;
+    std::memset(&A, 0, sizeof(A));
+    bh::rf_fill_launch(A.P, par->p, par->gauss, n, par->fsamp, par->tshift, par->nsv, par->waveno, par->nout);
+    A.P.sigma = sigma;
+    A.P.out_off = par->out_off;
+    A.P.out_stride = out_stride;
+    A.P.Lmax = Lmax;
+    A.P.depth_input = depth_input;
+    A.P.M = pick_rf_M(B, Lmax, n);
+    if (bh::rf_lds_bytes(Lmax, n, 1) > 160 * 1024) return fail_arg("model does not fit LDS");
+    rc = get_twiddles(n, &A.tw);
+    if (rc) return rc;
+    A.B = B; A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.qp = qp; A.qs = qs;
+    A.out = out;
+    BH_HIP(bh::launch_rf(A, (hipStream_t)stream));
+    return BH_OK;
+}
+
+int bh_rf_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
+                const double *vs, const double *rho, const double *qp, const double *qs,
+                const bh_rf_params *par, double *out, int out_stride, void *, size_t, void *stream)
+{
+    return rf_launch_common(B, Lmax, nlay, h, vp, vs, rho, qp, qs, par, std::nan(""), 0, out,
+                            out_stride, stream);
+}
+
+// ---- single-model drop-ins ------------------------------------------------------------------
+namespace {
+struct Scratch {  // per-thread device scratch for the synchronous single-model calls
+    void *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= n) return BH_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        BH_HIP(hipMalloc(&p, bytes));
+        n = bytes;
+        return BH_OK;
+    }
+};
+thread_local Scratch g_scratch;
+}  // namespace
+
+int bh_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                  int nlayer, int iflsph, int iwave, int mode, int igr, int kmax, const double *t,
+                  double *cg, int *err)
+{
+    if (!thkm || !vpm || !vsm || !rhom || !t || !cg || !err) return fail_arg("NULL pointer");
+    if (nlayer < 1 || nlayer > BH_MAX_LAYERS) return fail_arg("nlayer out of range (max 100)");
+    if (kmax < 0 || kmax > BH_MAX_PERIODS) return fail_arg("kmax out of range (max 60)");
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int L = nlayer;
+    // host staging: [h|vp|vs|rho] fp64 (exactly representable fp32 values), periods, nlay
+    std::vector<double> hb(4 * (size_t)L + BH_MAX_PERIODS);
+    for (int i = 0; i < L; i++) {
+        hb[i] = thkm[i]; hb[L + i] = vpm[i]; hb[2 * L + i] = vsm[i]; hb[3 * L + i] = rhom[i];
+    }
+    for (int k = 0; k < kmax; k++) hb[4 * L + k] = t[k];
+    size_t off_out = hb.size() * sizeof(double);
+    size_t off_ws = off_out + BH_MAX_PERIODS * sizeof(double);
+    size_t off_int = off_ws + 2 * BH_MAX_PERIODS * sizeof(double);
+    size_t total = off_int + 2 * sizeof(int);
+    rc = g_scratch.ensure(total);
+    if (rc) return rc;
+    char *d = (char *)g_scratch.p;
+    BH_HIP(hipMemcpy(d, hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice));
+    int ints[2] = {nlayer, 0};
+    BH_HIP(hipMemcpy(d + off_int, ints, sizeof(ints), hipMemcpyHostToDevice));
+    bh_swd_target tg = {iwave, igr, mode, iflsph, kmax, 0, 0, 0};
+    const double *dm = (const double *)d;
+    rc = bh_swd_batch(1, L, (const int *)(d + off_int), dm, dm + L, dm + 2 * L, dm + 3 * L, 1, &tg,
+                      dm + 4 * L, (double *)(d + off_out), BH_MAX_PERIODS, (int *)(d + off_int) + 1,
+                      d + off_ws, 2 * BH_MAX_PERIODS * sizeof(double), nullptr);
+    if (rc) return rc;
+    BH_HIP(hipDeviceSynchronize());
+    if (kmax > 0) BH_HIP(hipMemcpy(cg, d + off_out, kmax * sizeof(double), hipMemcpyDeviceToHost));
+    BH_HIP(hipMemcpy(err, (int *)(d + off_int) + 1, sizeof(int), hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
+int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double nsv, double sigma,
+             int waveno, int nlay, const double *z, const double *vp, const double *vs,
+             const double *rh, const double *qp, const double *qs, double *fz, double *fr, double *rf)
+{
+    if (!z || !vp || !vs || !rh || !qp || !qs || !rf) return fail_arg("NULL pointer");
+    if (fz || fr)
+        return fail_arg("fz/fr (vertical/radial traces) are not produced; pass NULL "
+                        "(BayHunter discards them, rfmini_modrf.py:134-142)");
+    if (nlay < 1 || nlay > BH_MAX_LAYERS) return fail_arg("nlay out of range (max 100)");
+    if (nsamp < 8 || nsamp > 4096) return fail_arg("nsamp out of range");
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int L = nlay;
+    std::vector<double> hb(6 * (size_t)L);
+    for (int i = 0; i < L; i++) {
+        hb[i] = z[i]; hb[L + i] = vp[i]; hb[2 * L + i] = vs[i]; hb[3 * L + i] = rh[i];
+        hb[4 * L + i] = qp[i]; hb[5 * L + i] = qs[i];
+    }
+    size_t off_out = hb.size() * sizeof(double);
+    size_t off_int = off_out + (size_t)nsamp * sizeof(double);
+    rc = g_scratch.ensure(off_int + sizeof(int));
+    if (rc) return rc;
+    char *d = (char *)g_scratch.p;
+    BH_HIP(hipMemcpy(d, hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice));
+    BH_HIP(hipMemcpy(d + off_int, &nlay, sizeof(int), hipMemcpyHostToDevice));
+    bh_rf_params par;
+    std::memset(&par, 0, sizeof(par));
+    par.p = p; par.gauss = a; par.fsamp = fsamp; par.tshift = tshift; par.nsv = nsv;
+    par.nsamp = nsamp; par.waveno = waveno; par.nout = nsamp; par.out_off = 0;
+    const double *dm = (const double *)d;
+    rc = rf_launch_common(1, L, (const int *)(d + off_int), dm, dm + L, dm + 2 * L, dm + 3 * L,
+                          dm + 4 * L, dm + 5 * L, &par, sigma, 1, (double *)(d + off_out), nsamp, nullptr);
+    if (rc) return rc;
+    BH_HIP(hipDeviceSynchronize());
+    BH_HIP(hipMemcpy(rf, d + off_out, (size_t)nsamp * sizeof(double), hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
+// ---- plumbing ----------------------------------------------------------------------------------
+int bh_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr) return fail_arg("dptr is NULL");
+    int rc = ensure_device();
+    if (rc) return rc;
+    BH_HIP(hipMalloc(dptr, bytes));
+    return BH_OK;
+}
+int bh_free(void *dptr)
+{
+    BH_HIP(hipFree(dptr));
+    return BH_OK;
+}
+int bh_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    BH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return BH_OK;
+}
+int bh_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    BH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return BH_OK;
+}
+int bh_stream_synchronize(void *stream)
+{
+    BH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BH_OK;
+}
+
+}  // extern "C"

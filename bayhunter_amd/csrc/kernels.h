@@ -1,0 +1,40 @@
+// kernels.h -- kernel argument blocks and launchers shared by kernels.hip and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rf_core.h"
+#include "swd_core.h"
+
+namespace bh {
+
+constexpr int SWD_T = 64;   // one wave per workgroup: a lane's search length is data dependent, so
+                            // single-wave groups retire (and free their LDS) independently
+constexpr int RF_T = 256;
+constexpr int BH_NP = 60;   // NP, surfdisp96.f:62
+constexpr int BH_NL = 100;  // NL, surfdisp96.f:60
+constexpr int BH_NT = 16;   // BH_MAX_TARGETS
+
+struct SwdArgs {
+    int B, Lmax, ntargets, out_stride;
+    const int *nlay;
+    const double *h, *vp, *vs, *rho;
+    const double *periods;
+    double *out;
+    int *err;
+    double *ws;
+    SwdTargetDev tg[BH_NT];
+};
+
+struct RfArgs {
+    int B;
+    const int *nlay;
+    const double *h, *vp, *vs, *rho, *qp, *qs;
+    const double *tw;  // FFT twiddles, rf_host.h
+    double *out;
+    RfLaunch P;
+};
+
+hipError_t launch_swd(const SwdArgs &A, hipStream_t stream);
+hipError_t launch_rf(const RfArgs &A, hipStream_t stream);
+size_t rf_lds_bytes(int Lmax, int nsamp, int M);
+
+}  // namespace bh

@@ -1,0 +1,44 @@
+// rf_host.h -- host-side preparation of the RF launch constants and the FFT twiddle table.
+// Everything here is evaluated with the reference's own expressions (cited) on the host, so the
+// device consumes bit-identical constants.
+#pragma once
+#include <cmath>
+#include <complex>
+#include "rf_core.h"
+
+namespace bh {
+
+inline void rf_fill_launch(RfLaunch &P, double p, double gauss, int nsamp, double fsamp,
+                           double tshift, double nsv, int waveno, int nout)
+{
+    P.slowness = p * 0.00899;                                  // wrap.cpp:55,76
+    P.p2 = P.slowness * P.slowness;                            // greens.cpp:421
+    P.gauss = gauss;
+    P.tshift = tshift;
+    P.nsv = nsv;
+    P.dw = 2.0 * M_PI * fsamp / nsamp;                         // greens.cpp:360,507
+    P.qgauss = std::sqrt(M_PI) * fsamp / gauss;                // greens.cpp:361
+    P.sc = std::sqrt(1. / (double)nsamp);                      // fork.cpp:28
+    P.qn = 1. / std::sqrt((double)nsamp);                      // greens.cpp:147
+    P.wref = 2. * M_PI * 1.;                                   // greens.cpp:447 with fref = 1 (synrf.cpp:25)
+    P.nsamp = nsamp;
+    P.nfreq = nsamp / 2 + 1;
+    P.log2n = 0;
+    while ((1 << P.log2n) < nsamp) P.log2n++;
+    P.waveno = waveno;
+    P.nout = nout;
+}
+
+// tw[2*(l+m)], tw[2*(l+m)+1] = exp(i*pi*m/l) for l = 1,2,4,..,n/2 and m < l  (fork.cpp:50-51, signi=+1)
+inline void rf_fill_twiddles(double *tw, int nsamp)
+{
+    tw[0] = tw[1] = 0.0;
+    for (int l = 1; l < nsamp; l <<= 1)
+        for (int m = 0; m < l; m++) {
+            std::complex<double> w = std::exp(std::complex<double>(0.0, M_PI * (double)(1 * m) / (double)l));
+            tw[2 * (l + m)] = w.real();
+            tw[2 * (l + m) + 1] = w.imag();
+        }
+}
+
+}  // namespace bh

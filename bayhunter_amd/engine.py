@@ -1,0 +1,143 @@
+"""Batched forward engine: many layered models per launch, inputs and outputs resident in HBM.
+
+This is the entry point the reference does not have (it evaluates one model per call,
+src/Targets.py:314-347); the single-model plugin classes in surf96_modsw.py / rfmini_modrf.py are
+thin views on it.  torch is used only for device memory and streams.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SWD_REFS = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
+RF_REFS = {'prf': 0, 'seis': 0, 'srf': 1}
+
+
+def rf_obsparams(obsx, ref='prf'):
+    """fsamp, tshft, nsamp from the observed time axis (src/rfmini_modrf.py:41-62)."""
+    obsx = np.asarray(obsx, dtype=np.float64)
+    deltas = np.round((obsx[1:] - obsx[:-1]), 4)
+    if np.unique(deltas).size == 1:
+        dt = float(deltas[0])
+        fsamp = 1. / dt
+    else:
+        raise ValueError("Target: %s. Sampling rate must be constant." % ref)
+    tshft = -obsx[0]
+    nsamp = 2.**int(np.ceil(np.log2(obsx.size * 2)))
+    return fsamp, float(tshft), nsamp
+
+
+class SwdSpec(object):
+    def __init__(self, ref, periods, mode=1, flsph=0):
+        if ref not in SWD_REFS:
+            raise ReferenceError("Reference is not available in SurfDisp: %s" % ref)
+        self.ref = ref
+        self.iwave, self.igr = SWD_REFS[ref]
+        self.periods = np.ascontiguousarray(periods, dtype=np.float64)
+        if self.periods.size > _lib.MAX_PERIODS:
+            raise ValueError("at most 60 periods per call (surfdisp96.f:62); resample like "
+                             "SurfDisp does for longer vectors")
+        self.mode, self.flsph = int(mode), int(flsph)
+
+
+class RfSpec(object):
+    def __init__(self, ref, obsx, gauss=1.0, p=6.4, nsv=None):
+        if ref not in RF_REFS:
+            raise ReferenceError("Reference is not available in RFminiModRF: %s" % ref)
+        self.ref = ref
+        self.waveno = RF_REFS[ref]
+        self.obsx = np.ascontiguousarray(obsx, dtype=np.float64)
+        self.fsamp, self.tshft, self.nsamp = rf_obsparams(self.obsx, ref)
+        self.gauss, self.p, self.nsv = float(gauss), float(p), nsv
+
+
+class ForwardEngine(object):
+    """All targets of a joint inversion for a batch of models in (at most) two launches.
+
+    Output row of model b: [swd target 0 | swd target 1 | ... | rf target 0 | ...], fp64.
+    """
+
+    def __init__(self, swd=(), rf=(), device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.BayHunterAmdError("no HIP device visible to torch; there is no CPU fallback")
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        self.swd = list(swd)
+        self.rf = list(rf)
+        if len(self.swd) > _lib.MAX_TARGETS:
+            raise ValueError("too many SWD targets")
+        off = 0
+        per_off = 0
+        self._tg = (_lib.SwdTarget * max(1, len(self.swd)))()
+        pers = []
+        self.slices = []
+        for t, s in enumerate(self.swd):
+            self._tg[t] = _lib.SwdTarget(s.iwave, s.igr, s.mode, s.flsph, s.periods.size,
+                                         per_off, off, 0)
+            self.slices.append(slice(off, off + s.periods.size))
+            pers.append(s.periods)
+            off += s.periods.size
+            per_off += s.periods.size
+        self._rfp = []
+        for r in self.rf:
+            nout = r.obsx.size
+            self._rfp.append(_lib.RfParams(r.p, r.gauss, r.fsamp, r.tshft,
+                                           -1.0 if r.nsv is None else float(r.nsv),
+                                           int(r.nsamp), r.waveno, nout, off))
+            self.slices.append(slice(off, off + nout))
+            off += nout
+        self.row = off
+        with torch.cuda.device(self.device):
+            self.periods = torch.from_numpy(
+                np.concatenate(pers) if pers else np.zeros(1)).to(self.device)
+        self._ws = None
+
+    # -- helpers
+    def _as_dev(self, x, dtype):
+        if isinstance(x, torch.Tensor):
+            if x.device != self.device or x.dtype != dtype or not x.is_contiguous():
+                x = x.to(device=self.device, dtype=dtype).contiguous()
+            return x
+        return torch.from_numpy(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
+
+    def upload(self, H, VP, VS, RHO, nlay):
+        """Host arrays [B, Lmax] (+ int nlay[B]) -> device tensors."""
+        f64 = torch.float64
+        return (self._as_dev(H, f64), self._as_dev(VP, f64), self._as_dev(VS, f64),
+                self._as_dev(RHO, f64), self._as_dev(nlay, torch.int32))
+
+    def alloc_out(self, B):
+        out = torch.empty((B, self.row), dtype=torch.float64, device=self.device)
+        err = torch.empty((B, max(1, len(self.swd))), dtype=torch.int32, device=self.device)
+        return out, err
+
+    def run(self, H, VP, VS, RHO, nlay, out=None, err=None, stream=None):
+        """Launch all targets for the batch (asynchronous).  Returns (out[B,row], err[B,nswd])."""
+        H, VP, VS, RHO, nlay = self.upload(H, VP, VS, RHO, nlay)
+        B, Lmax = H.shape
+        if out is None or err is None:
+            out, err = self.alloc_out(B)
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        sp = C.c_void_p(st.cuda_stream)
+        with torch.cuda.device(self.device):
+            if self.swd:
+                need = self.lib.bh_swd_workspace_bytes(B, len(self.swd), self._tg)
+                ws_ptr = None
+                if need:
+                    if self._ws is None or self._ws.numel() * 8 < need:
+                        self._ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
+                    ws_ptr = self._ws.data_ptr()
+                _lib.check(self.lib.bh_swd_batch(
+                    B, Lmax, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
+                    RHO.data_ptr(), len(self.swd), self._tg, self.periods.data_ptr(),
+                    out.data_ptr(), self.row, err.data_ptr(), ws_ptr, need, sp))
+            else:
+                err.zero_()
+            for rp in self._rfp:
+                _lib.check(self.lib.bh_rf_batch(
+                    B, Lmax, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
+                    RHO.data_ptr(), None, None, C.byref(rp), out.data_ptr(), self.row, None, 0, sp))
+        return out, err

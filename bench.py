@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""bench.py -- forward evaluations per second of the BayHunter likelihood hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched through
+torch.distributed.run, one rank per GPU) prints ONE JSON line on rank 0.
+
+A "step" is one pass of the hot path over one batch of synthetic layered models that is already
+resident in HBM: all dispersion targets of the workload (swd kernel) + the receiver function
+(rf kernel) for every model of the rank's shard.  One "evaluation" = all targets of one model
+(SURVEY.md section 8d).  Chains are independent, so ranks shard the models with no data-path
+collective (weak scaling: the per-GPU batch is fixed); the only collectives are the timing barrier
+and the MAX over ranks.
+
+Workloads (BASELINE.json):
+  joint10  (default; the configuration the metric "forward evals/sec (SWD+RF, 10-layer)" is quoted
+           on) Rayleigh phase velocity at 21 periods + P receiver function (201 samples @ 5 Hz,
+           nsamp 512), 10-layer models
+  cfg2     Rayleigh phase only, 5 layers, 20 periods, 1024 models
+  cfg3     Rayleigh+Love x phase+group, 10 layers, 40 periods, 8192 models
+  cfg4     Rayleigh phase (21) + P-RF, 15 layers, 64 models per GPU
+  cfg5     ragged 2..31 layers, Rayleigh phase (21) + P-RF
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (spec), SURVEY.md 8d
+F_RAYLEIGH, F_LOVE = 190.0, 30.0   # flop per layer step of the period equation
+
+WORKLOADS = {
+    #           layers        swd refs                                     periods rf    batch/GPU  cfg id
+    'joint10': dict(L=10, refs=['rdispph'], P=21, rf=True, B=16384, cfg=6),
+    'cfg2':    dict(L=5, refs=['rdispph'], P=20, rf=False, B=1024, cfg=2),
+    'cfg3':    dict(L=10, refs=['rdispph', 'rdispgr', 'ldispph', 'ldispgr'], P=40, rf=False, B=8192, cfg=3),
+    'cfg4':    dict(L=15, refs=['rdispph'], P=21, rf=True, B=64, cfg=4),
+    'cfg5':    dict(L=(2, 31), refs=['rdispph'], P=21, rf=True, B=8192, cfg=5),
+}
+REF_TAGS = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
+
+
+def make_models(wl, B, rank):
+    from bayhunter_amd.synthetic import draw_models
+    return draw_models(B, wl['L'], seed=1000 * wl['cfg'] + rank, sorted_vs=True)
+
+
+def algorithmic_bytes(wl, Lmean):
+    """32*L + 4 (model) + 8*sum(n_out) + 4*ntargets (err), per evaluation, split by
+    kernel (each kernel reads the model once)."""
+    model = 32.0 * Lmean + 4
+    swd = model + sum(8.0 * wl['P'] + 4 for _ in wl['refs'])
+    rf = (model + 8.0 * 201) if wl['rf'] else 0.0
+    return swd, rf
+
+
+# ------------------------------------------------------------------------------------ CPU baseline
+def _cpu_worker(args):
+    wl_name, n, seed, use_ref = args
+    from oracle import pyoracle as po
+    from bayhunter_amd.synthetic import draw_models
+    wl = WORKLOADS[wl_name]
+    H, VP, VS, RHO, nl = draw_models(n, wl['L'], seed=seed, sorted_vs=True)
+    per = np.linspace(1, 41, wl['P'])
+    backend = 'ref' if use_ref else 'port'
+    t0 = time.perf_counter()
+    for ref in wl['refs']:
+        iw, ig = REF_TAGS[ref]
+        po.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, backend=backend)
+    if wl['rf']:
+        po.rf_batch(H, VP, VS, RHO, nl, backend=backend)
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(wl_name, per_core=None):
+    """Reference native code (oracle/_ref, kind "reference") or the C restatement (kind "port")
+    on all host cores of this box, one process per core, on a bounded sample of the same workload.
+    Runs in a child process tree that never touches the GPU."""
+    import multiprocessing as mp
+    from oracle import pyoracle as po
+    use_ref = po.have_ref()
+    if not use_ref:
+        po.port_lib()
+    cores = len(os.sched_getaffinity(0))
+    wl = WORKLOADS[wl_name]
+    if per_core is None:
+        # ~10 s per core at the reference's measured single-core rates
+        cost = (len(wl['refs']) * wl['P'] / 21.0 * 0.5e-3 + (0.85e-3 if wl['rf'] else 0)) * \
+               (np.mean(wl['L']) / 10.0)
+        per_core = int(max(64, min(20000, 10.0 / cost)))
+    ctx = mp.get_context('fork')
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(wl_name, per_core, 555000 + i, use_ref) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    n = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return {"value": n / busy, "unit": "evals/s", "cores": cores,
+            "kind": "reference" if use_ref else "port",
+            "per_core": n / sum(r[1] for r in res),
+            "sample": "%d models (%d per core, %d processes), workload %s, %.1f s wall"
+                      % (n, per_core, cores, wl_name, wall)}
+
+
+def n_dltar_sample(wl):
+    """Period-equation evaluations per model of the reference path (counted in the oracle, whose
+    search is the reference's step for step) on 128 benchmark-seed models."""
+    from oracle import pyoracle as po
+    from bayhunter_amd.synthetic import draw_models
+    H, VP, VS, RHO, nl = draw_models(128, wl['L'], seed=1000 * wl['cfg'], sorted_vs=True)
+    per = np.linspace(1, 41, wl['P'])
+    counts = {}
+    for ref in wl['refs']:
+        iw, ig = REF_TAGS[ref]
+        _, _, nc = po.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, nthreads=4)
+        counts[ref] = nc / 128.0
+    return counts, float(np.mean(nl))
+
+
+# ----------------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='joint10', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='models per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true')
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.workload)))
+        return
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+
+    # CPU baseline first, in a child that never initialises the GPU (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only',
+                            '--workload', args.workload], capture_output=True, text=True)
+        if r.returncode == 0:
+            cpu = json.loads(r.stdout.strip().splitlines()[-1])
+        else:
+            sys.stderr.write('cpu baseline failed: %s\n' % r.stderr[-2000:])
+
+    import torch
+    import torch.distributed as dist
+    from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+
+    B = args.batch or wl['B']
+    per = np.linspace(1, 41, wl['P'])
+    H, VP, VS, RHO, nl = make_models(wl, B, rank)
+    eng_swd = ForwardEngine(swd=[SwdSpec(r, per) for r in wl['refs']])
+    row = eng_swd.row
+    eng_rf = None
+    if wl['rf']:
+        eng_rf = ForwardEngine(rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
+    dH, dVP, dVS, dRHO, dnl = eng_swd.upload(H, VP, VS, RHO, nl)       # inputs resident in HBM
+    out_swd, err = eng_swd.alloc_out(B)
+    out_rf = eng_rf.alloc_out(B)[0] if eng_rf else None
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        eng_swd.run(dH, dVP, dVS, dRHO, dnl, out=out_swd, err=err)
+        if i is not None:
+            ev[i][1].record()
+        if eng_rf:
+            eng_rf.run(dH, dVP, dVS, dRHO, dnl, out=out_rf, err=err)
+        if i is not None:
+            ev[i][2].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_swd = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_rf = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if eng_rf else 0.0
+    nerr = int(err.sum().item())
+
+    if rank == 0:
+        counts, Lmean = n_dltar_sample(wl)
+        bytes_swd, bytes_rf = algorithmic_bytes(wl, Lmean)
+        flop_swd = sum(counts[r] * (Lmean - 1) * (F_RAYLEIGH if REF_TAGS[r][0] == 2 else F_LOVE)
+                       for r in wl['refs'])
+        flop_rf = (257 * (Lmean - 1) * 500 + Lmean * 300 + 257 * 60 + 5 * 512 * 9) if wl['rf'] else 0.0
+        dom_is_swd = ms_swd >= ms_rf
+        dom_ms = ms_swd if dom_is_swd else ms_rf
+        dom_bytes = (bytes_swd if dom_is_swd else bytes_rf) * B
+        dom_flop = (flop_swd if dom_is_swd else flop_rf) * B
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        value = world * B * args.steps / dt
+        res = {
+            "metric": "forward evals/sec (SWD+RF, 10-layer)" if args.workload == 'joint10'
+                      else "forward evals/sec (%s)" % args.workload,
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s%s, %s layers, %d periods, %d models/GPU/step"
+                                   % (args.workload, '+'.join(wl['refs']),
+                                      '+prf(201 samples, nsamp 512)' if wl['rf'] else '',
+                                      str(wl['L']), wl['P'], B),
+                       "models_per_gpu": B, "sharding": "models block-partitioned over ranks, no data-path collective",
+                       "err_models": nerr},
+            "roofline": {"kernel": "swd_kernel" if dom_is_swd else "rf_kernel", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
+                         "note": "fp64 scalar recurrence: the binding limit is FP64 VALU issue + "
+                                 "transcendental latency, see fp64_valu"},
+            "fp64_valu": {"achieved": dom_flop / (dom_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                          "unit": "TFLOP/s",
+                          "frac": dom_flop / (dom_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                          "flop_per_eval_reference_path": flop_swd + flop_rf,
+                          "n_dltar_per_eval": counts},
+            "kernels_ms": {"swd_kernel": ms_swd, "rf_kernel": ms_rf},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,120 @@
+/*
+ * bayhunter_amd.h -- C ABI of libbayhunter_amd.so, the MI355X (gfx950) forward-modelling engine
+ * for BayHunter's per-proposal likelihood hot path.
+ *
+ * Boundary being replaced (reference file:line, paths relative to the BayHunter tree):
+ *   - f2py symbol   err = surfdisp96(thkm,vpm,vsm,rhom,nlayer,iflsph,iwave,mode,igr,kmax,t,cg)
+ *                   src/extensions/surfdisp96.f:55-56, called at src/surf96_modsw.py:116-117
+ *   - Cython/C      synrf_cwrap(nsamp,fsamp,tshift,p,a,nsv,sigma,waveno,nlay,z,vp,vs,rh,qp,qs,fz,fr,rf)
+ *                   src/extensions/rfmini/wrap.cpp:57-63, called through rfmini.pyx:74-114 from
+ *                   src/rfmini_modrf.py:134-137
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer; no allocation crosses the ABI
+ *   - `*_batch` entry points take DEVICE pointers and a HIP stream (hipStream_t passed as void*;
+ *     NULL = the default stream) and are asynchronous
+ *   - `bh_surfdisp96` / `bh_synrf` take HOST pointers, copy, launch, and synchronise: they are the
+ *     drop-in for the two reference symbols above (same argument meaning, same failure semantics)
+ *   - return value: BH_OK, or an error code for API misuse / HIP failures.  A model for which the
+ *     solver finds no root is NOT an error of the call: it is reported per model in `err[]`
+ *     exactly like the reference's `err` (surfdisp96.f:313-316,348-354)
+ *   - every function fails with BH_ERR_NO_DEVICE when no gfx950 device is usable: there is no
+ *     CPU fallback in this library
+ */
+#ifndef BAYHUNTER_AMD_H
+#define BAYHUNTER_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_OK            0
+#define BH_ERR_ARG       1 /* bad argument (sizes, NULL pointers, limits)           */
+#define BH_ERR_HIP       2 /* a HIP runtime call failed; see bh_last_error()        */
+#define BH_ERR_NO_DEVICE 3 /* no usable HIP device                                  */
+#define BH_ERR_WORKSPACE 4 /* workspace too small; see the *_workspace_bytes helper */
+
+#define BH_MAX_LAYERS  100 /* NL, surfdisp96.f:60 */
+#define BH_MAX_PERIODS 60  /* NP, surfdisp96.f:62 */
+#define BH_MAX_TARGETS 16
+
+/* One surface-wave target = one (wave type, velocity type) dispersion curve, i.e. one SurfDisp
+ * plugin instance of the reference (surf96_modsw.py:24-34,48-59). */
+typedef struct bh_swd_target {
+    int iwave;   /* 1 = Love, 2 = Rayleigh                      (surfdisp96.f:75)      */
+    int igr;     /* 0 = phase velocity, >0 = group velocity     (surfdisp96.f:77)      */
+    int mode;    /* 1 = fundamental, 2 = first higher, ...      (surfdisp96.f:76)      */
+    int iflsph;  /* 0 = flat earth, 1 = earth-flattening        (surfdisp96.f:74)      */
+    int nper;    /* number of periods, <= BH_MAX_PERIODS        (kmax, surfdisp96.f:78) */
+    int per_off; /* offset of this target's periods in `periods`                       */
+    int out_off; /* first column of this target in a model's output row                */
+    int _pad;
+} bh_swd_target;
+
+/* Receiver-function parameters = RFminiModRF.modelparams + the values derived from the observed
+ * time axis (rfmini_modrf.py:26-62,99-142). */
+typedef struct bh_rf_params {
+    double p;       /* slowness in s/deg                                  ('p')     */
+    double gauss;   /* Gauss filter parameter a                           ('gauss') */
+    double fsamp;   /* sampling frequency in Hz                                      */
+    double tshift;  /* time shift in s                                               */
+    double nsv;     /* near-surface S velocity; <= 0: take vs of the top layer ('nsv' None) */
+    int    nsamp;   /* FFT length, power of two, 8..4096                             */
+    int    waveno;  /* 0 = P, 1 = SV                                       ('wtype') */
+    int    nout;    /* number of leading samples returned (= obsx.size)              */
+    int    out_off; /* first column of the RF in a model's output row                */
+} bh_rf_params;
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char *bh_version(void);
+const char *bh_last_error(void);          /* text of the last BH_ERR_HIP on this thread     */
+int  bh_device_count(int *count);
+int  bh_set_device(int device);
+
+/* ---- batched surface-wave dispersion (device pointers) ---------------------------------- */
+/* Models: fp64 row-major [B][Lmax] arrays h, vp, vs, rho and int32 nlay[B] (layers incl. the
+ * half-space, 1 <= nlay <= Lmax <= BH_MAX_LAYERS).  They are rounded to fp32 on load exactly like
+ * f2py does for the reference (surf96_modsw.py:68-82).  `targets` is a HOST array.
+ * out[b*out_stride + out_off + k], k < nper: phase/group velocity; failed and later periods are 0.
+ * err[b*ntargets + t]: the reference's err flag for that (model, target).
+ * workspace: only needed when some target has mode > 1 (bh_swd_workspace_bytes). */
+size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets);
+int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
+                 const double *vs, const double *rho, int ntargets, const bh_swd_target *targets,
+                 const double *periods, double *out, int out_stride, int *err,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- batched receiver functions (device pointers) --------------------------------------- */
+/* qp/qs may be NULL: 500 / 225 like rfmini_modrf.py:119-120.  Output: the first nout samples of
+ * the RF trace at out[b*out_stride + out_off + i].  NaN propagates like in the reference. */
+size_t bh_rf_workspace_bytes(int B, int Lmax, const bh_rf_params *par);
+int bh_rf_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
+                const double *vs, const double *rho, const double *qp, const double *qs,
+                const bh_rf_params *par, double *out, int out_stride,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- single-model drop-ins (host pointers, synchronous) --------------------------------- */
+/* Same argument list as the f2py wrapper of `subroutine surfdisp96`; model arrays are real*4 with
+ * at least nlayer valid entries, t/cg real*8 with at least kmax entries.  *err as the reference. */
+int bh_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                  int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                  const double *t, double *cg, int *err);
+/* Same argument list as synrf_cwrap (wrap.cpp:57-63).  fz/fr may be NULL. Returns BH_OK, not 1. */
+int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double nsv, double sigma,
+             int waveno, int nlay, const double *z, const double *vp, const double *vs,
+             const double *rh, const double *qp, const double *qs,
+             double *fz, double *fr, double *rf);
+
+/* ---- plumbing for hosts without their own device allocator ------------------------------ */
+int bh_malloc(void **dptr, size_t bytes);
+int bh_free(void *dptr);
+int bh_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int bh_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int bh_stream_synchronize(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYHUNTER_AMD_H */

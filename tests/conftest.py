@@ -1,0 +1,85 @@
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """The CPU oracle (plain-C restatement), compiled on demand."""
+    from oracle import pyoracle
+    pyoracle.port_lib()
+    return pyoracle
+
+
+@pytest.fixture(scope='session')
+def lib():
+    """The in-tree HIP library (built on demand; hipcc cross-compiles without a GPU)."""
+    import bayhunter_amd
+    bayhunter_amd.build()
+    return bayhunter_amd.load()
+
+
+@pytest.fixture(scope='session')
+def hostsim():
+    """g++ build of the device solver cores, run lane by lane on the CPU (tests only)."""
+    d = os.path.join(ROOT, 'tests', 'hostsim')
+    so = os.path.join(d, 'libhostsim.so')
+    srcs = [os.path.join(d, 'hostsim.cpp')] + [
+        os.path.join(ROOT, 'bayhunter_amd', 'csrc', f)
+        for f in ('bh_common.h', 'swd_core.h', 'rf_core.h', 'rf_host.h')]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+                        '-o', so, srcs[0]], check=True)
+    hs = C.CDLL(so)
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    hs.hs_surfdisp96.restype = C.c_int
+    hs.hs_surfdisp96.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, dp, dp, C.POINTER(C.c_long)]
+    hs.hs_rf.restype = C.c_int
+    hs.hs_rf.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int,
+                         C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp]
+
+    class HS(object):
+        @staticmethod
+        def swd(h, vp, vs, rho, per, iw, ig, mode=1, fl=0):
+            f = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32))
+                 for x in (h, vp, vs, rho)]
+            t = np.ascontiguousarray(per, dtype=np.float64)
+            cg = np.zeros(len(t))
+            nc = C.c_long(0)
+            e = hs.hs_surfdisp96(*[x.ctypes.data_as(fp) for x in f], len(h), fl, iw, mode, ig,
+                                 len(t), t.ctypes.data_as(dp), cg.ctypes.data_as(dp), C.byref(nc))
+            return cg, e, nc.value
+
+        @staticmethod
+        def rf(h, vp, vs, rho, p=6.4, gauss=1.0, nsamp=512, fsamp=5.0, tshift=5.0, nsv=None,
+               waveno=0, nout=201):
+            a = [np.ascontiguousarray(x, dtype=np.float64) for x in (h, vp, vs, rho)]
+            out = np.zeros(nout)
+            hs.hs_rf(len(a[0]), *[x.ctypes.data_as(dp) for x in a], None, None, p, gauss, nsamp,
+                     fsamp, tshift, -1.0 if nsv is None else nsv, waveno, nout,
+                     out.ctypes.data_as(dp))
+            return out
+    return HS
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return {name: np.load(os.path.join(GOLDEN, name + '.npz'))
+            for name in ('swd_rf_random', 'swd_variants', 'rf_variants', 'tutorial_full')}
+
+
+REFS = [('rdispph', 2, 0), ('rdispgr', 2, 1), ('ldispph', 1, 0), ('ldispgr', 1, 1)]
+SETS = ['L%d_%s' % (L, s) for L in (2, 5, 10, 15, 31) for s in ('sorted', 'lvz')]

@@ -1,0 +1,75 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE ONLY.
+// Compiles the device solver cores (bayhunter_amd/csrc/*_core.h) with g++ and runs them lane by
+// lane on the CPU, so that the control-flow transformation of the kernels (state machine around a
+// single period-equation call site; task-parallel reflectivity + LDS FFT) can be checked bit for
+// bit against the oracle without a GPU.  Never loaded by the bayhunter_amd package.
+#define BH_HOSTSIM 1
+#include <cstring>
+#include <vector>
+#include "../../bayhunter_amd/csrc/swd_core.h"
+#include "../../bayhunter_amd/csrc/rf_core.h"
+#include "../../bayhunter_amd/csrc/rf_host.h"
+
+namespace {
+struct HostLay {
+    float *pd, *pa, *pb, *pr;
+    float d(int i) const { return pd[i]; }
+    float a(int i) const { return pa[i]; }
+    float b(int i) const { return pb[i]; }
+    float rho(int i) const { return pr[i]; }
+    void set_d(int i, float v) { pd[i] = v; }
+    void set_a(int i, float v) { pa[i] = v; }
+    void set_b(int i, float v) { pb[i] = v; }
+    void set_rho(int i, float v) { pr[i] = v; }
+};
+}  // namespace
+
+extern "C" int hs_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                             int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                             const double *t, double *cg, long *ncalls)
+{
+    std::vector<float> d(thkm, thkm + nlayer), a(vpm, vpm + nlayer), b(vsm, vsm + nlayer),
+        r(rhom, rhom + nlayer);
+    HostLay lay{d.data(), a.data(), b.data(), r.data()};
+    bh::SwdTargetDev tg{iwave, igr, mode, iflsph, kmax, 0, 0, 0};
+    std::vector<double> cws(kmax > 0 ? kmax : 1), cbws(kmax > 0 ? kmax : 1);
+    return bh::swd_lane(lay, nlayer, tg, t, cg, cws.data(), cbws.data(), 1, ncalls);
+}
+
+namespace bh {
+// CPU replay of the RF workgroup program (P1..P4) for one model; mirrors rf_kernels.hip.
+static int rf_hostsim_model(int nlay, const double *h, const double *vp, const double *vs,
+                            const double *rho, const double *qp, const double *qs, double p,
+                            double gauss, int nsamp, double fsamp, double tshift, double nsv,
+                            int waveno, int nout, double *rf)
+{
+    RfLaunch P;
+    std::memset(&P, 0, sizeof(P));
+    rf_fill_launch(P, p, gauss, nsamp, fsamp, tshift, nsv, waveno, nout);
+    P.sigma = std::nan("");
+    P.Lmax = nlay;
+    RfLayout lo = rf_layout(nlay, nsamp);
+    std::vector<double> S(lo.per_model, 0.0), tw(2 * (size_t)nsamp, 0.0);
+    rf_fill_twiddles(tw.data(), nsamp);
+    for (int i = 0; i < nlay; i++) rf_phase1_layer(S.data(), lo, nlay, i, h, vp, vs, rho, qp, qs, 0);
+    for (int i = 0; i < nlay; i++) rf_phase2_interface(S.data(), lo, P, nlay, i, vp[0], vs[0]);
+    std::vector<cd> spec(P.nfreq);
+    for (int j = 0; j < P.nfreq; j++) spec[j] = rf_phase3_task(S.data(), lo, P, nlay, j);
+    double *X = S.data();
+    for (int j = 0; j < P.nfreq; j++) st_cd(X + 2 * j, spec[j]);
+    for (int i = nsamp / 2 + 1; i < nsamp; i++) rf_fft_hermitian(X, nsamp, i);
+    for (int i = 0; i < nsamp; i++) rf_fft_bitrev_scale(X, nsamp, P.log2n, P.sc, i);
+    for (int l = 1; l < nsamp; l <<= 1)
+        for (int bf = 0; bf < nsamp / 2; bf++) rf_fft_butterfly(X, tw.data(), l, bf);
+    for (int i = 0; i < nout; i++) rf[i] = P.qn * X[2 * i];
+    return 0;
+}
+}  // namespace bh
+
+extern "C" int hs_rf(int nlay, const double *h, const double *vp, const double *vs, const double *rho,
+                     const double *qp, const double *qs, double p, double gauss, int nsamp,
+                     double fsamp, double tshift, double nsv, int waveno, int nout, double *rf)
+{
+    return bh::rf_hostsim_model(nlay, h, vp, vs, rho, qp, qs, p, gauss, nsamp, fsamp, tshift, nsv,
+                                waveno, nout, rf);
+}

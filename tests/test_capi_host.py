@@ -1,0 +1,100 @@
+"""CPU tier: the C-ABI library loads, exports every symbol the header declares, refuses to compute
+without a GPU (no CPU fallback), and the Python host side mirrors the reference's plugin contract."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'bayhunter_amd.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(bh_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_header_symbols_exported(lib):
+    from bayhunter_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True,
+                         text=True, check=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if ' T ' in l)
+    for s in declared:
+        assert s in exported, s
+        assert hasattr(lib, s)
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_no_torch_types_in_abi():
+    txt = open(os.path.join(ROOT, 'include', 'bayhunter_amd.h')).read()
+    assert 'torch' not in txt and 'at::' not in txt and 'hipStream_t' in txt  # mentioned in prose only
+    assert re.search(r'void \*stream', txt)
+
+
+def test_product_never_touches_oracle():
+    """The shipped package and library must not import, link or call the oracle / host simulator."""
+    pkg = os.path.join(ROOT, 'bayhunter_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                src = open(os.path.join(dp, f)).read()
+                assert 'pyoracle' not in src and 'liboracle' not in src and 'bho_' not in src, f
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+                assert 'libhostsim' not in src, f
+    from bayhunter_amd import _lib
+    out = subprocess.run(['ldd', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'oracle' not in out and 'hostsim' not in out
+
+
+def test_arg_validation_without_gpu(lib):
+    from bayhunter_amd import _lib
+    import ctypes as C
+    tg = (_lib.SwdTarget * 1)(_lib.SwdTarget(3, 0, 1, 0, 21, 0, 0, 0))
+    rc = lib.bh_swd_batch(4, 101, 1, 1, 1, 1, 1, 1, tg, 1, 1, 21, 1, None, 0, None)
+    assert rc == _lib.BH_ERR_ARG
+    assert lib.bh_swd_workspace_bytes(100, 1, tg) == 0
+    tg[0].mode = 2
+    assert lib.bh_swd_workspace_bytes(100, 1, tg) == 100 * 2 * 60 * 8
+    n = C.c_int(-1)
+    assert lib.bh_device_count(C.byref(n)) == 0 and n.value >= 0
+
+
+def test_fails_loudly_without_device(lib):
+    import bayhunter_amd as bh
+    if bh.device_count() > 0:
+        pytest.skip('a GPU is present')
+    sd = bh.SurfDisp(np.linspace(1, 41, 21), 'rdispph')
+    with pytest.raises(bh.BayHunterAmdError):
+        sd.run_model(np.array([5., 0.]), np.array([5., 7.]), np.array([3., 4.]), np.array([2.4, 3.]))
+    rf = bh.RFminiModRF(np.linspace(-5, 35, 201), 'prf')
+    with pytest.raises(bh.BayHunterAmdError):
+        rf.run_model(np.array([5., 0.]), np.array([5., 7.]), np.array([3., 4.]), np.array([2.4, 3.]))
+
+
+def test_plugin_contract():
+    """ctor (obsx, ref), ref -> (iwave, igr) map, ReferenceError, modelparams keys, obs params
+    (reference: surf96_modsw.py:24-66, rfmini_modrf.py:17-62)."""
+    import bayhunter_amd as bh
+    x = np.linspace(1, 41, 21)
+    tags = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
+    for ref, t in tags.items():
+        sd = bh.SurfDisp(x, ref)
+        assert (sd.wavetype, sd.veltype) == t and sd.kmax == 21
+        assert sd.modelparams == {'mode': 1, 'flsph': 0}
+    with pytest.raises(ReferenceError):
+        bh.SurfDisp(x, 'xdisp')
+    sd = bh.SurfDisp(np.linspace(2, 80, 75), 'rdispph')
+    assert sd.obsx_int.size == 60 and sd.obsx_int[0] == 2 and sd.obsx_int[-1] == 80
+    sd.set_modelparams(mode=2)
+    assert sd.modelparams['mode'] == 2
+
+    rf = bh.RFminiModRF(np.linspace(-5, 35, 201), 'prf')
+    assert rf.modelparams == {'wtype': 'P', 'gauss': 1.0, 'p': 6.4, 'water': 0.001, 'nsv': None}
+    assert abs(rf.fsamp - 5.0) < 1e-12 and rf.tshft == 5.0 and rf.nsamp == 512
+    assert bh.RFminiModRF(np.linspace(-5, 35, 201), 'srf').modelparams['wtype'] == 'SV'
+    with pytest.raises(ValueError):
+        bh.RFminiModRF(np.array([0., 0.2, 0.5, 0.6]), 'prf')

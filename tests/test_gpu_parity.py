@@ -1,0 +1,233 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden
+vectors.
+
+Tolerances (fp64 path; device libm differs from glibc in the last bits, nothing else does):
+  * phase velocity  : the reference returns dble(sngl(c)) -> outputs are fp32-representable; the
+                      replayed search ends on the same fp32 value except when the fp64 root sits on
+                      a rounding boundary: |diff| <= 1 fp32 ulp (4.8e-7 at c in [4,8)), and >= 99 %
+                      of the values bit-identical
+  * group velocity  : fp32 finite difference of two roots, amplifies a 1-ulp change by ~1/(2h)=100:
+                      |diff| <= 1e-4, >= 98 % bit-identical
+  * err flags       : identical
+  * receiver function: |diff| <= 1e-10 (observed ~1e-14)
+  * north_star      : RMS misfit of every curve against the reference within 1e-6 (TOL_MISFIT)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bayhunter_amd.synthetic import draw_models, tutorial_model
+from conftest import GOLDEN, REFS, SETS
+
+pytestmark = pytest.mark.gpu
+
+TOL_PHASE = 4.8e-7
+TOL_GROUP = 1.0e-4
+TOL_RF = 1.0e-10
+TOL_MISFIT = 1.0e-6
+
+
+def _nlay(model):
+    return np.array([int((m > 0).sum()) for m in model[2]], dtype=np.int32)
+
+
+def _engine(refs, per, rf=False, **kw):
+    from bayhunter_amd.engine import ForwardEngine, SwdSpec, RfSpec
+    return ForwardEngine(swd=[SwdSpec(r, per, **kw) for r in refs],
+                         rf=[RfSpec('prf', np.linspace(-5, 35, 201))] if rf else [])
+
+
+def _check_swd(name, got, want, err_got, err_want):
+    assert np.array_equal(err_got, err_want), name
+    d = np.abs(got - want)
+    tol = TOL_GROUP if name.endswith('gr') else TOL_PHASE
+    frac = float((got == want).mean())
+    assert d.max() <= tol, (name, d.max())
+    assert frac >= (0.98 if name.endswith('gr') else 0.99), (name, frac)
+    rms = np.sqrt(np.mean((got - want) ** 2, axis=1))
+    assert rms.max() <= TOL_MISFIT, (name, rms.max())
+
+
+@pytest.mark.parametrize('tag', SETS + ['ragged'])
+def test_golden_sets(lib, golden, tag):
+    g = golden['swd_rf_random']
+    H, VP, VS, RHO = g[tag + '_model']
+    nl = g['ragged_nlay'] if tag == 'ragged' else _nlay(g[tag + '_model'])
+    eng = _engine([r[0] for r in REFS], g['periods'], rf=True)
+    out, err = eng.run(H, VP, VS, RHO, nl)
+    out, err = out.cpu().numpy(), err.cpu().numpy()
+    for t, (name, _, _) in enumerate(REFS):
+        _check_swd(name, out[:, eng.slices[t]], g[tag + '_' + name], err[:, t], g[tag + '_' + name + '_err'])
+    rf = out[:, eng.slices[4]]
+    want = g[tag + '_prf']
+    assert np.array_equal(np.isnan(rf), np.isnan(want))
+    assert np.nanmax(np.abs(rf - want)) <= TOL_RF
+
+
+def test_swd_variants(lib, golden):
+    g = golden['swd_variants']
+    H, VP, VS, RHO = g['model']
+    nl = _nlay(g['model'])
+    per = np.linspace(1, 41, 21)
+    for mode in (1, 2, 3):
+        for fl in (0, 1):
+            eng = _engine([r[0] for r in REFS], per, mode=mode, flsph=fl)
+            out, err = eng.run(H, VP, VS, RHO, nl)
+            out, err = out.cpu().numpy(), err.cpu().numpy()
+            for t, (name, _, _) in enumerate(REFS):
+                key = '%s_m%d_f%d' % (name, mode, fl)
+                got, want = out[:, eng.slices[t]], g[key]
+                assert np.array_equal(err[:, t], g[key + '_err']), key
+                # flsph=1 goes through a device powf: rho differs by an fp32 ulp -> looser bound
+                tol = (TOL_GROUP if name.endswith('gr') else TOL_PHASE) * (50 if fl else 1)
+                assert np.abs(got - want).max() <= tol, (key, np.abs(got - want).max())
+    for P in (20, 40, 60):
+        eng = _engine([r[0] for r in REFS], np.linspace(1, 41, P))
+        out, err = eng.run(H, VP, VS, RHO, nl)
+        out, err = out.cpu().numpy(), err.cpu().numpy()
+        for t, (name, _, _) in enumerate(REFS):
+            _check_swd(name, out[:, eng.slices[t]], g['%s_P%d' % (name, P)], err[:, t], g['%s_P%d_err' % (name, P)])
+
+
+def test_rf_variants(lib, golden):
+    from bayhunter_amd.engine import ForwardEngine, RfSpec
+    g = golden['rf_variants']
+    H, VP, VS, RHO = g['model']
+    nl = _nlay(g['model'])
+    worst = 0.0
+    for key in g.files:
+        if key == 'model':
+            continue
+        w, gs, p, n, nsv = key.split('_')
+        n = int(n[1:])
+        x = np.arange(n // 2) / 5.0 - 5.0            # n/2 samples at 5 Hz -> nsamp = n
+        eng = ForwardEngine(rf=[RfSpec('prf' if w == 'w0' else 'srf', x, float(gs[1:]), float(p[1:]),
+                                       3.0 if nsv == 'nsv' else None)])
+        assert int(eng.rf[0].nsamp) == n
+        out, _ = eng.run(H, VP, VS, RHO, nl)
+        d = np.abs(out.cpu().numpy() - g[key]).max()
+        worst = max(worst, d)
+        assert d <= TOL_RF, (key, d)
+    print('rf variants worst |diff| = %.3e' % worst)
+
+
+def test_tutorial_dataset_single_model_dropins(lib, golden):
+    """north_star: misfit within 1e-6 of SURF96/rfmini on the tutorial dataset, through the
+    single-model drop-ins (bh_surfdisp96 / bh_synrf) behind the plugin classes."""
+    import bayhunter_amd as bh
+    h, vp, vs, rho = tutorial_model()
+    per = np.linspace(1, 41, 21)
+    full = golden['tutorial_full']
+    for name, _, _ in REFS:
+        obs = np.loadtxt(os.path.join(GOLDEN, 'tutorial_observed', 'st3_%s.dat' % name))
+        x, y = bh.SurfDisp(per, name).run_model(h, vp, vs, rho)
+        assert np.array_equal(x, per)
+        assert np.abs(y - full[name]).max() <= (TOL_GROUP if name.endswith('gr') else TOL_PHASE)
+        mis_ref = np.sqrt(np.mean((full[name] - obs[:, 1]) ** 2))
+        mis_gpu = np.sqrt(np.mean((y - obs[:, 1]) ** 2))
+        assert abs(mis_ref - mis_gpu) <= TOL_MISFIT
+        assert np.abs(y - obs[:, 1]).max() <= 5.1e-5
+    for name in ('prf', 'srf'):
+        obs = np.loadtxt(os.path.join(GOLDEN, 'tutorial_observed', 'st3_%s.dat' % name))
+        t, y = bh.RFminiModRF(obs[:, 0], name).run_model(h, vp, vs, rho)
+        assert np.allclose(t, obs[:, 0])
+        assert np.abs(y - full[name]).max() <= TOL_RF
+        mis_ref = np.sqrt(np.mean((full[name] - obs[:, 1]) ** 2))
+        mis_gpu = np.sqrt(np.mean((y - obs[:, 1]) ** 2))
+        assert abs(mis_ref - mis_gpu) <= TOL_MISFIT
+
+
+def test_failure_semantics_and_nan(lib, oracle):
+    """err flags, zero fill, (nan, nan) from run_model, NaN model terminates."""
+    import bayhunter_amd as bh
+    per = np.linspace(1, 41, 21)
+    H, VP, VS, RHO, nl = draw_models(512, 6, seed=77, sorted_vs=False)
+    want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, 2, 0)
+    sd = bh.SurfDisp(per, 'rdispph')
+    x, Y, e = sd.run_models(H, VP, VS, RHO, nl)
+    assert np.array_equal(e, werr) and 0 < e.sum() < 256
+    assert np.all(np.isnan(Y[e != 0])) and np.abs(Y[e == 0] - want[werr == 0]).max() <= TOL_PHASE
+    b = int(np.nonzero(werr)[0][0])
+    n = nl[b]
+    xm, ym = sd.run_model(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n])
+    assert np.isnan(xm) and np.isnan(ym)
+    # NaN velocity: must end (no root), not hang
+    vs = np.array([3.0, np.nan, 4.5])
+    xm, ym = sd.run_model(np.array([5., 10., 0.]), vs * 1.73, vs, vs * 1.73 * .32 + .77)
+    assert np.isnan(xm)
+
+
+def test_edge_shapes(lib, oracle):
+    """B=1, B not a multiple of the workgroup, 1- and 2-layer models, 100 layers, 1 and 60 periods."""
+    per = np.linspace(1, 41, 21)
+    for B, L in ((1, 4), (63, 3), (65, 2), (130, 7)):
+        H, VP, VS, RHO, nl = draw_models(B, L, seed=B * 10 + L)
+        eng = _engine(['rdispph', 'ldispgr'], per, rf=True)
+        out, err = eng.run(H, VP, VS, RHO, nl)
+        out, err = out.cpu().numpy(), err.cpu().numpy()
+        for t, (iw, ig) in enumerate(((2, 0), (1, 1))):
+            want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, iw, ig)
+            assert np.array_equal(err[:, t], werr)
+            assert np.abs(out[:, eng.slices[t]] - want).max() <= (TOL_GROUP if ig else TOL_PHASE)
+        assert np.abs(out[:, eng.slices[2]] - oracle.rf_batch(H, VP, VS, RHO, nl)).max() <= TOL_RF
+    # half-space only: Love has no root (err=1), RF is NaN (greens.cpp:208,572)
+    H, VP, VS, RHO, nl = draw_models(3, 1, seed=5)
+    eng = _engine(['rdispph', 'ldispph'], per, rf=True)
+    out, err = eng.run(H, VP, VS, RHO, nl)
+    out, err = out.cpu().numpy(), err.cpu().numpy()
+    for t, iw in enumerate((2, 1)):
+        want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, iw, 0)
+        assert np.array_equal(err[:, t], werr) and np.abs(out[:, eng.slices[t]] - want).max() <= TOL_PHASE
+    assert np.all(np.isnan(out[:, eng.slices[2]]))
+    # 100 layers (NL), 60 periods (NP), single period
+    H, VP, VS, RHO, nl = draw_models(5, 100, seed=6, zmax=300.0, thickmin=0.05)
+    for P in (1, 60):
+        p = np.linspace(2, 50, P)
+        eng = _engine(['rdispph'], p, rf=(P == 1))
+        out, err = eng.run(H, VP, VS, RHO, nl)
+        want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, p, 2, 0)
+        assert np.array_equal(err.cpu().numpy()[:, 0], werr)
+        assert np.abs(out.cpu().numpy()[:, :P] - want).max() <= TOL_PHASE
+        if P == 1:
+            assert np.abs(out.cpu().numpy()[:, 1:] - oracle.rf_batch(H, VP, VS, RHO, nl)).max() <= TOL_RF
+
+
+def test_more_than_60_periods_interpolation(lib, oracle):
+    import bayhunter_amd as bh
+    h, vp, vs, rho = tutorial_model()
+    x = np.linspace(2, 40, 75)
+    sd = bh.SurfDisp(x, 'rdispph')
+    xm, ym = sd.run_model(h, vp, vs, rho)
+    want, err = oracle.swd(h, vp, vs, rho, sd.obsx_int, 2, 0)
+    assert err == 0 and np.array_equal(xm, x)
+    assert np.abs(ym - np.interp(x, sd.obsx_int, want)).max() <= TOL_PHASE
+
+
+def test_full_size_properties(lib, oracle):
+    """BASELINE cfg3 size (8192 models x 10 layers x 4 targets x 40 periods) + RF: properties that
+    do not need the oracle on every model, plus an oracle spot check on a slice."""
+    import torch
+    per = np.linspace(1, 41, 40)
+    H, VP, VS, RHO, nl = draw_models(8192, 10, seed=3000)
+    eng = _engine([r[0] for r in REFS], per, rf=True)
+    out, err = eng.run(H, VP, VS, RHO, nl)
+    out2, err2 = eng.run(H, VP, VS, RHO, nl)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(err, err2)          # deterministic / idempotent
+    o, e = out.cpu().numpy(), err.cpu().numpy()
+    assert e.sum() == 0                                               # sorted-Vs models always solve
+    vsmin, vsmax = VS[:, 0], VS[:, -1]
+    for t in range(4):
+        c = o[:, eng.slices[t]]
+        assert np.all(c > 0.8 * 0.9 * vsmin[:, None]) and np.all(c <= vsmax[:, None] * 1.0001)
+    assert np.all(o[:, eng.slices[0]] == o[:, eng.slices[0]].astype(np.float32))  # dble(sngl(c))
+    # permutation equivariance: a model's result does not depend on its slot / neighbours
+    perm = np.random.RandomState(1).permutation(8192)
+    outp, _ = eng.run(H[perm], VP[perm], VS[perm], RHO[perm], nl[perm])
+    assert np.array_equal(outp.cpu().numpy(), o[perm], equal_nan=True)
+    sl = slice(4000, 4064)
+    for t, (name, iw, ig) in enumerate(REFS):
+        want, werr, _ = oracle.swd_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl], per, iw, ig)
+        _check_swd(name, o[sl, eng.slices[t]], want, e[sl, t], werr)
+    assert np.abs(o[sl, eng.slices[4]] - oracle.rf_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl])).max() <= TOL_RF

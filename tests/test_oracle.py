@@ -1,0 +1,130 @@
+"""CPU tier: the oracle (plain-C restatement) against every pin we have.
+
+1. golden vectors produced by the reference's own native code (tests/golden/make_golden.py):
+   bit-exact;
+2. the data files shipped with the reference's tutorial (4-decimal): to the rounding of the files
+   for dispersion (5e-5), 1e-4 for the receiver functions (files stem from an older rfmini build,
+   SURVEY.md section 4);
+3. when oracle/_ref is present (development container), live bitwise comparison on fresh seeds.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bayhunter_amd.synthetic import draw_models, tutorial_model
+from conftest import GOLDEN, REFS, SETS
+
+
+def _nlay(model):
+    return np.array([int((m > 0).sum()) for m in model[2]], dtype=np.int32)  # vs > 0 marks a layer
+
+
+@pytest.mark.parametrize('tag', SETS)
+def test_swd_golden_bitexact(oracle, golden, tag):
+    g = golden['swd_rf_random']
+    H, VP, VS, RHO = g[tag + '_model']
+    nl = _nlay(g[tag + '_model'])
+    for name, iw, ig in REFS:
+        out, err, _ = oracle.swd_batch(H, VP, VS, RHO, nl, g['periods'], iw, ig)
+        assert np.array_equal(err, g[tag + '_' + name + '_err'])
+        assert np.array_equal(out, g[tag + '_' + name])
+
+
+@pytest.mark.parametrize('tag', SETS)
+def test_rf_golden_bitexact(oracle, golden, tag):
+    g = golden['swd_rf_random']
+    H, VP, VS, RHO = g[tag + '_model']
+    nl = _nlay(g[tag + '_model'])
+    out = oracle.rf_batch(H, VP, VS, RHO, nl)
+    assert np.array_equal(out, g[tag + '_prf'], equal_nan=True)
+
+
+def test_ragged_golden_bitexact(oracle, golden):
+    g = golden['swd_rf_random']
+    H, VP, VS, RHO = g['ragged_model']
+    nl = g['ragged_nlay']
+    for name, iw, ig in REFS:
+        out, err, _ = oracle.swd_batch(H, VP, VS, RHO, nl, g['periods'], iw, ig)
+        assert np.array_equal(err, g['ragged_' + name + '_err'])
+        assert np.array_equal(out, g['ragged_' + name])
+    assert np.array_equal(oracle.rf_batch(H, VP, VS, RHO, nl), g['ragged_prf'], equal_nan=True)
+
+
+def test_swd_variants_golden(oracle, golden):
+    g = golden['swd_variants']
+    H, VP, VS, RHO = g['model']
+    nl = _nlay(g['model'])
+    per = np.linspace(1, 41, 21)
+    for name, iw, ig in REFS:
+        for mode in (1, 2, 3):
+            for fl in (0, 1):
+                out, err, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, mode, fl)
+                key = '%s_m%d_f%d' % (name, mode, fl)
+                assert np.array_equal(err, g[key + '_err']), key
+                assert np.array_equal(out, g[key]), key
+        for P in (20, 40, 60):
+            out, err, _ = oracle.swd_batch(H, VP, VS, RHO, nl, np.linspace(1, 41, P), iw, ig)
+            assert np.array_equal(out, g['%s_P%d' % (name, P)])
+
+
+def test_rf_variants_golden(oracle, golden):
+    g = golden['rf_variants']
+    H, VP, VS, RHO = g['model']
+    nl = _nlay(g['model'])
+    for key in g.files:
+        if key == 'model':
+            continue
+        w, gs, p, n, nsv = key.split('_')
+        out = oracle.rf_batch(H, VP, VS, RHO, nl, float(p[1:]), float(gs[1:]), int(n[1:]), 5.0, 5.0,
+                              3.0 if nsv == 'nsv' else None, int(w[1:]), nout=int(n[1:]) // 2)
+        assert np.array_equal(out, g[key], equal_nan=True), key
+
+
+def test_tutorial_files(oracle, golden):
+    """The reference's own shipped vectors (tutorial/observed/st3_*.dat)."""
+    h, vp, vs, rho = tutorial_model()
+    per = np.linspace(1, 41, 21)
+    full = golden['tutorial_full']
+    for name, iw, ig in REFS:
+        obs = np.loadtxt(os.path.join(GOLDEN, 'tutorial_observed', 'st3_%s.dat' % name))
+        assert np.allclose(obs[:, 0], per)
+        out, err = oracle.swd(h, vp, vs, rho, per, iw, ig)
+        assert err == 0
+        assert np.abs(out - obs[:, 1]).max() <= 5.0e-5 + 1e-12
+        assert np.array_equal(out, full[name])
+    for name, wn in (('prf', 0), ('srf', 1)):
+        obs = np.loadtxt(os.path.join(GOLDEN, 'tutorial_observed', 'st3_%s.dat' % name))
+        out = oracle.rf_model(h, vp, vs, rho, waveno=wn, nout=201)
+        assert np.allclose(obs[:, 0], np.linspace(-5, 35, 201))
+        assert np.abs(out - obs[:, 1]).max() <= 1.0e-4
+        assert np.array_equal(out, full[name])
+    mod = np.loadtxt(os.path.join(GOLDEN, 'tutorial_observed', 'st3_mod.dat'), skiprows=1)
+    assert np.allclose(mod[:, 1], vp, atol=5e-5) and np.allclose(mod[:, 3], rho, atol=5e-5)
+
+
+def test_failure_semantics(oracle):
+    """err=1 and zero-fill from the failing period on (surfdisp96.f:313-354)."""
+    H, VP, VS, RHO, nl = draw_models(300, 6, seed=77, sorted_vs=False)
+    out, err, _ = oracle.swd_batch(H, VP, VS, RHO, nl, np.linspace(1, 41, 21), 2, 0)
+    assert 0 < err.sum() < 150
+    for b in np.nonzero(err)[0]:
+        z = np.nonzero(out[b] == 0.0)[0]
+        assert z.size > 0 and np.all(out[b, z[0]:] == 0.0)
+    assert np.all(out[err == 0] > 0)
+
+
+def test_live_against_reference(oracle):
+    if not oracle.have_ref():
+        pytest.skip('oracle/_ref not built (reference tree absent)')
+    per = np.linspace(1, 41, 21)
+    H, VP, VS, RHO, nl = draw_models(40, (2, 20), seed=4242, sorted_vs=False)
+    for name, iw, ig in REFS:
+        for mode, fl in ((1, 0), (2, 0), (1, 1)):
+            a, ea, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, mode, fl, backend='port')
+            r, er, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, mode, fl, backend='ref')
+            assert np.array_equal(ea, er) and np.array_equal(a, r)
+    for wn in (0, 1):
+        a = oracle.rf_batch(H, VP, VS, RHO, nl, waveno=wn, backend='port')
+        r = oracle.rf_batch(H, VP, VS, RHO, nl, waveno=wn, backend='ref')
+        assert np.array_equal(a, r, equal_nan=True)
