@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
 SOURCES = ["kernels.hip", "capi.hip"]
-HEADERS = ["bh_common.h", "swd_core.h", "rf_core.h", "rf_host.h", "kernels.h"]
+HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "rf_core.h", "rf_host.h", "kernels.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 

@@ -28,9 +28,7 @@ using std::fabs;
 using std::log;
 using std::sin;
 using std::sqrt;
-BH_DEV void bh_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
 #else
-BH_DEV void bh_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
 #endif
 
 BH_DEV double dsign1(double x) { return copysign(1.0, x); }
@@ -93,12 +91,6 @@ BH_DEV cd csqrt_(cd z)
     return mk(r, copysign(s, im));
 }
 
-BH_DEV cd cexp_(cd z)
-{
-    double s, c, e = exp(z.re);
-    bh_sincos(z.im, &s, &c);
-    return mk(e * c, e * s);
-}
 
 // ---- complex 2x2 (rfmini cmat2.h) ------------------------------------------------------------
 struct cm2 {

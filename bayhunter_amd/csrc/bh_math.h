@@ -1,0 +1,115 @@
+// bh_math.h -- lean fp64 sincos / exp for the solver cores.
+//
+// The reference calls glibc's sin, cos, exp (through dsin/dcos/dexp and std::complex).  No device
+// libm reproduces those bit for bit, so the only requirement here is accuracy (< 1 ulp, measured
+// against glibc in tests/test_hostsim.py::test_math_accuracy) -- and a short instruction stream:
+// the period equation spends half of its instructions in these three functions, and a wave whose
+// lanes straddle the oscillatory/evanescent branch of surfdisp96.f:929-968 pays for both sides.
+//
+//   bh_sincos : one-step Cody-Waite reduction by pi/2 (fdlibm's 33+53-bit split, exact with FMA)
+//               valid for |x| < 1e4 (max error 1.04 ulp, 0.79 below 300), then the classic __kernel_sin/__kernel_cos minimax
+//               polynomials on [-pi/4, pi/4] with the reduction tail folded in.  Larger arguments
+//               (never produced by physical models: p = k_z * d) fall back to the slow path.
+//   bh_exp    : k = rint(x/ln2), r = x - k*ln2 (hi/lo, exact with FMA), degree-13 polynomial,
+//               scaled by 2^k with ldexp; saturates like exp() outside [-745, 709].
+#pragma once
+#include "bh_common.h"
+
+namespace bh {
+
+#if defined(BH_HOSTSIM)
+BH_DEV double bh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+BH_DEV double bh_rint(double x) { return __builtin_rint(x); }
+BH_DEV double bh_ldexp(double x, int k) { return __builtin_ldexp(x, k); }
+BH_DEV void bh_sincos_slow(double x, double *s, double *c) { *s = std::sin(x); *c = std::cos(x); }
+#else
+BH_DEV double bh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+BH_DEV double bh_rint(double x) { return __builtin_rint(x); }
+BH_DEV double bh_ldexp(double x, int k) { return __builtin_amdgcn_ldexp(x, k); }
+BH_DEV void bh_sincos_slow(double x, double *s, double *c) { ::sincos(x, s, c); }
+#endif
+
+#if defined(BH_HOSTSIM) && defined(BH_HOSTSIM_GLIBC_MATH)
+// tests/hostsim "exact" build: glibc's functions, so that the replay is bit-identical to the oracle
+BH_DEV void bh_sincos(double x, double *sn, double *cs) { *sn = std::sin(x); *cs = std::cos(x); }
+BH_DEV double bh_exp(double x) { return std::exp(x); }
+#else
+BH_DEV void bh_sincos(double x, double *sn, double *cs)
+{
+    const double INVPIO2 = 6.36619772367581382433e-01;  // 2/pi
+    const double PIO2_1 = 1.57079632673412561417e+00;   // first 33 bits of pi/2
+    const double PIO2_1T = 6.07710050650619224932e-11;  // pi/2 - PIO2_1
+    if (!(fabs(x) < 1.0e4)) {  // also NaN/Inf; beyond 1e4 the two-constant reduction exceeds 1 ulp
+        bh_sincos_slow(x, sn, cs);
+        return;
+    }
+    double fn = bh_rint(x * INVPIO2);
+    double r = bh_fma(-fn, PIO2_1, x);  // exact: fn < 2^20, PIO2_1 has 33 significant bits
+    double w = fn * PIO2_1T;
+    double y0 = r - w;
+    double y1 = (r - y0) - w;           // tail: x - fn*pi/2 = y0 + y1
+    int n = (int)fn;
+    double z = y0 * y0;
+    // __kernel_sin(y0, y1, 1)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double v = z * y0;
+    double rs = bh_fma(z, bh_fma(z, bh_fma(z, bh_fma(z, S6, S5), S4), S3), S2);
+    double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    // __kernel_cos(y0, y1)
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double ww = z * z;
+    double rc = z * bh_fma(z, bh_fma(z, C3, C2), C1) + (ww * ww) * bh_fma(z, bh_fma(z, C6, C5), C4);
+    double hz = 0.5 * z;
+    double w1 = 1.0 - hz;
+    double c = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
+    // quadrant
+    double so = (n & 1) ? c : s;
+    double co = (n & 1) ? s : c;
+    *sn = (n & 2) ? -so : so;
+    *cs = ((n + 1) & 2) ? -co : co;
+}
+
+BH_DEV double bh_exp(double x)
+{
+    const double LOG2E = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;  // 32 significant bits
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double xc = x;
+    if (xc > 710.0) xc = 710.0;      // -> +inf through ldexp
+    if (xc < -746.0) xc = -746.0;    // -> 0
+    double k = bh_rint(xc * LOG2E);
+    double r = bh_fma(-k, LN2_HI, xc);
+    r = bh_fma(-k, LN2_LO, r);
+    // exp(r) on |r| <= ln2/2: Taylor to degree 13 (truncation 4e-18)
+    double p = 1.6059043836821613e-10;                  // 1/13!
+    p = bh_fma(p, r, 2.08767569878681e-09);             // 1/12!
+    p = bh_fma(p, r, 2.505210838544172e-08);            // 1/11!
+    p = bh_fma(p, r, 2.755731922398589e-07);            // 1/10!
+    p = bh_fma(p, r, 2.7557319223985893e-06);           // 1/9!
+    p = bh_fma(p, r, 2.48015873015873e-05);             // 1/8!
+    p = bh_fma(p, r, 1.984126984126984e-04);            // 1/7!
+    p = bh_fma(p, r, 1.3888888888888889e-03);           // 1/6!
+    p = bh_fma(p, r, 8.333333333333333e-03);            // 1/5!
+    p = bh_fma(p, r, 4.1666666666666664e-02);           // 1/4!
+    p = bh_fma(p, r, 1.6666666666666666e-01);           // 1/3!
+    p = bh_fma(p, r, 0.5);
+    p = bh_fma(p, r, 1.0);
+    p = bh_fma(p, r, 1.0);
+    double res = bh_ldexp(p, (int)k);
+    return (x != x) ? x : res;
+}
+#endif
+
+// exp(z) = e^re (cos im + i sin im), the formulation of glibc's cexp for finite arguments
+BH_DEV cd cexp_(cd z)
+{
+    double s, c, e = bh_exp(z.re);
+    bh_sincos(z.im, &s, &c);
+    return mk(e * c, e * s);
+}
+
+}  // namespace bh

@@ -30,7 +30,8 @@ struct LdsLay {
     __device__ __forceinline__ void set_rho(int i, float v) { base[(3 * L + i) * SWD_T] = v; }
 };
 
-__global__ __launch_bounds__(SWD_T) void swd_kernel(SwdArgs A)
+// 2 waves per SIMD: the search state + one Dunkin layer need ~250 VGPRs; pin the allocator there
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_kernel(SwdArgs A)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;

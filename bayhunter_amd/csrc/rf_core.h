@@ -22,6 +22,7 @@
 // matrix e are dropped from products (adds of exact zeros).
 #pragma once
 #include "bh_common.h"
+#include "bh_math.h"
 
 namespace bh {
 

@@ -16,6 +16,7 @@
 // (build with -ffp-contract=off).
 #pragma once
 #include "bh_common.h"
+#include "bh_math.h"
 
 namespace bh {
 
@@ -39,7 +40,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
     } else {
         pex = p;
         fac = 0.0;
-        if (p < 16) fac = exp(-2.0 * p);
+        if (p < 16) fac = bh_exp(-2.0 * p);
         cosp = (1.0 + fac) * 0.5;
         sinp = (1.0 - fac) * 0.5;
         w = sinp / ra;
@@ -54,7 +55,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
     } else {
         sex = q;
         fac = 0.0;
-        if (q < 16) fac = exp(-2.0 * q);
+        if (q < 16) fac = bh_exp(-2.0 * q);
         cosq = (1.0 + fac) * 0.5;
         sinq = (1.0 - fac) * 0.5;
         y = sinq / rb;
@@ -62,7 +63,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
     }
     double exa = pex + sex;
     double a0 = 0.0;
-    if (exa < 60.0) a0 = exp(-exa);
+    if (exa < 60.0) a0 = bh_exp(-exa);
     o.a0 = a0;
     o.cpcq = cosp * cosq; o.cpy = cosp * y; o.cpz = cosp * z;
     o.cqw = cosq * w;     o.cqx = cosq * x;
@@ -207,7 +208,7 @@ BH_DEV double swd_dltar1(const Lay &lay, int mmax, int llw, double wvno, double 
             cosq = 1.0; y = dm; z = 0.0;
         } else {
             fac = 0.0;
-            if (q < 16) fac = exp(-2.0 * q);
+            if (q < 16) fac = bh_exp(-2.0 * q);
             cosq = (1.0 + fac) * 0.5;
             sinq = (1.0 - fac) * 0.5;
             y = sinq / rb;

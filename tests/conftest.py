@@ -31,18 +31,19 @@ def lib():
     return bayhunter_amd.load()
 
 
-@pytest.fixture(scope='session')
-def hostsim():
-    """g++ build of the device solver cores, run lane by lane on the CPU (tests only)."""
+def _build_hostsim(name, extra):
     d = os.path.join(ROOT, 'tests', 'hostsim')
-    so = os.path.join(d, 'libhostsim.so')
+    so = os.path.join(d, name)
     srcs = [os.path.join(d, 'hostsim.cpp')] + [
         os.path.join(ROOT, 'bayhunter_amd', 'csrc', f)
-        for f in ('bh_common.h', 'swd_core.h', 'rf_core.h', 'rf_host.h')]
+        for f in ('bh_common.h', 'bh_math.h', 'swd_core.h', 'rf_core.h', 'rf_host.h')]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-                        '-o', so, srcs[0]], check=True)
-    hs = C.CDLL(so)
+        subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off'] + extra +
+                       ['-o', so, srcs[0]], check=True)
+    return C.CDLL(so)
+
+
+def _wrap_hostsim(hs):
     fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
     hs.hs_surfdisp96.restype = C.c_int
     hs.hs_surfdisp96.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -50,6 +51,8 @@ def hostsim():
     hs.hs_rf.restype = C.c_int
     hs.hs_rf.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int,
                          C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp]
+    hs.hs_sincos.argtypes = [C.c_int, dp, dp, dp]
+    hs.hs_exp.argtypes = [C.c_int, dp, dp]
 
     class HS(object):
         @staticmethod
@@ -72,7 +75,36 @@ def hostsim():
                      fsamp, tshift, -1.0 if nsv is None else nsv, waveno, nout,
                      out.ctypes.data_as(dp))
             return out
+
+        @staticmethod
+        def sincos(x):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            s_, c_ = np.zeros_like(x), np.zeros_like(x)
+            hs.hs_sincos(x.size, x.ctypes.data_as(dp), s_.ctypes.data_as(dp), c_.ctypes.data_as(dp))
+            return s_, c_
+
+        @staticmethod
+        def exp(x):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            y = np.zeros_like(x)
+            hs.hs_exp(x.size, x.ctypes.data_as(dp), y.ctypes.data_as(dp))
+            return y
     return HS
+
+
+@pytest.fixture(scope='session')
+def hostsim():
+    """g++ build of the device solver cores with glibc math: the replay must be bit-identical to
+    the oracle (tests only)."""
+    return _wrap_hostsim(_build_hostsim('libhostsim.so', ['-DBH_HOSTSIM_GLIBC_MATH']))
+
+
+@pytest.fixture(scope='session')
+def hostsim_devmath():
+    """Same cores with the device math of bh_math.h (software FMA through libm when the host
+    CPU build has none): what the GPU computes, up to ocml's sqrt/log (tests only)."""
+    fma = ['-mfma'] if ' fma ' in open('/proc/cpuinfo').read() else []
+    return _wrap_hostsim(_build_hostsim('libhostsim_devmath.so', fma))
 
 
 @pytest.fixture(scope='session')

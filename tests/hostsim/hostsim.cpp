@@ -73,3 +73,13 @@ extern "C" int hs_rf(int nlay, const double *h, const double *vp, const double *
     return bh::rf_hostsim_model(nlay, h, vp, vs, rho, qp, qs, p, gauss, nsamp, fsamp, tshift, nsv,
                                 waveno, nout, rf);
 }
+
+// accuracy probes for bh_math.h (tests/test_hostsim.py::test_math_accuracy)
+extern "C" void hs_sincos(int n, const double *x, double *s, double *c)
+{
+    for (int i = 0; i < n; i++) bh::bh_sincos(x[i], &s[i], &c[i]);
+}
+extern "C" void hs_exp(int n, const double *x, double *y)
+{
+    for (int i = 0; i < n; i++) y[i] = bh::bh_exp(x[i]);
+}

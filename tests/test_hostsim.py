@@ -43,3 +43,48 @@ def test_rf_workgroup_program(oracle, hostsim, wn):
             r = hostsim.rf(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], p, gauss, nsamp, 5.0, 5.0,
                            nsv, wn, 100)
             assert np.abs(a - r).max() <= 1e-12 * max(1.0, np.abs(a).max())
+
+
+def _ulp_err(got, x, fn):
+    ref = fn(x.astype(np.longdouble))
+    u = np.spacing(np.abs(ref.astype(np.float64)))
+    return np.abs((got.astype(np.longdouble) - ref) / u).astype(np.float64)
+
+
+def test_math_accuracy(hostsim_devmath):
+    """bh_math.h: < 1 ulp over the argument ranges the solvers produce, sane special values."""
+    rs = np.random.RandomState(0)
+    for lo, hi, bound in ((-1, 1, 0.85), (-300, 300, 0.85), (-1e4, 1e4, 1.1)):
+        x = rs.uniform(lo, hi, 400000)
+        s, c = hostsim_devmath.sincos(x)
+        assert _ulp_err(s, x, np.sin).max() <= bound and _ulp_err(c, x, np.cos).max() <= bound
+    x = np.array([0.0, 1e-300, 1e7, -1e9, np.pi / 2])
+    s, c = hostsim_devmath.sincos(x)
+    assert np.allclose(s, np.sin(x), rtol=0, atol=1e-15) and np.allclose(c, np.cos(x), rtol=0, atol=1e-15)
+    assert all(np.isnan(v).all() for v in hostsim_devmath.sincos(np.array([np.inf, np.nan])))
+    for lo, hi in ((-60, 0), (-700, 700)):
+        x = rs.uniform(lo, hi, 400000)
+        assert _ulp_err(hostsim_devmath.exp(x), x, np.exp).max() <= 0.95
+    with np.errstate(over='ignore'):
+        x = np.array([0.0, -0.0, -745.5, -800, 710, 800, np.inf, -np.inf])
+        assert np.array_equal(hostsim_devmath.exp(x), np.exp(x))
+    assert np.isnan(hostsim_devmath.exp(np.array([np.nan]))[0])
+
+
+def test_swd_device_math_parity(oracle, hostsim_devmath):
+    """With the device math the search still lands on the reference's values: bit-identical for
+    monotone models, inside the reference's 1e-6 stopping bracket for LVZ models."""
+    per = np.linspace(1, 41, 21)
+    for srt in (True, False):
+        H, VP, VS, RHO, nl = draw_models(40, 8, seed=900 + int(srt), sorted_vs=srt)
+        same = tot = 0
+        for name, iw, ig in REFS:
+            for b in range(40):
+                a, e1 = oracle.swd(H[b], VP[b], VS[b], RHO[b], per, iw, ig)
+                r, e2, _ = hostsim_devmath.swd(H[b], VP[b], VS[b], RHO[b], per, iw, ig)
+                assert e1 == e2
+                tol = 1.5e-3 if ig else 1.5e-6 * 5
+                assert np.abs(a - r).max() <= tol
+                same += int((a == r).sum())
+                tot += a.size
+        assert same / tot >= (0.999 if srt else 0.98)
