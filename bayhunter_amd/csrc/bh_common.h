@@ -36,6 +36,12 @@ BH_DEV double dmin(double a, double b) { return a < b ? a : b; }
 BH_DEV double dmax(double a, double b) { return a > b ? a : b; }
 
 // ---- complex fp64 --------------------------------------------------------------------------
+// Complex arithmetic is only used by the receiver-function path, which is tolerance-checked
+// (|diff| <= 1e-10, observed 1e-13): it may use FMA contraction.  The surface-wave path (real
+// arithmetic, exact replay) is compiled with contraction off.
+#if !defined(BH_HOSTSIM)
+#pragma clang fp contract(fast)
+#endif
 struct cd {
     double re, im;
 };
@@ -67,6 +73,13 @@ BH_DEV cd operator/(cd x, cd y)
     return mk(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
 }
 BH_DEV cd rdiv(double x, cd y) { return mk(x, 0.0) / y; }
+// 1/z = conj(z)/|z|^2: one real division instead of Smith's three; for the well-scaled values of
+// the per-frequency recursion (|z| within 1e-3..1e3)
+BH_DEV cd crecip(cd z)
+{
+    double r = 1.0 / (z.re * z.re + z.im * z.im);
+    return mk(z.re * r, -(z.im * r));
+}
 
 // principal square root, glibc csqrt's formulation for finite non-zero arguments
 BH_DEV cd csqrt_(cd z)
@@ -111,5 +124,9 @@ BH_DEV cm2 operator+(const cm2 &x, const cm2 &y)
     r.c11 = x.c11 + y.c11; r.c12 = x.c12 + y.c12; r.c21 = x.c21 + y.c21; r.c22 = x.c22 + y.c22;
     return r;
 }
+
+#if !defined(BH_HOSTSIM)
+#pragma clang fp contract(off)
+#endif
 
 }  // namespace bh

@@ -70,12 +70,41 @@ int get_twiddles(int nsamp, const double **out)
     return BH_OK;
 }
 
+// Work-queue heads for swd_kernel: a ring of slots per device so that launches in flight on
+// different streams never share a counter; each launch zeroes its slot on its own stream.
+constexpr int kQueueSlots = 256;
+struct DevState {
+    unsigned int *queue = nullptr;
+    unsigned long next = 0;
+    int cus = 0;
+};
+std::mutex g_dev_mutex;
+std::map<int, DevState> g_dev;
+
+int get_queue_slot(unsigned int **slot, int *resident_waves)
+{
+    int dev = 0;
+    BH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    DevState &d = g_dev[dev];
+    if (!d.queue) {
+        BH_HIP(hipMalloc((void **)&d.queue, (size_t)kQueueSlots * bh::BH_NT * sizeof(unsigned int)));
+        hipDeviceProp_t prop;
+        BH_HIP(hipGetDeviceProperties(&prop, dev));
+        d.cus = prop.multiProcessorCount;
+    }
+    *slot = d.queue + (size_t)(d.next++ % kQueueSlots) * bh::BH_NT;
+    *resident_waves = d.cus * 8;   // 2 waves/SIMD x 4 SIMDs (VGPR-limited, kernels.hip)
+    return BH_OK;
+}
+
 int pick_rf_M(int B, int Lmax, int nsamp)
 {
-    // as many models per workgroup as fit ~64 KiB of LDS (two workgroups per CU), at most 8: with
-    // nfreq = 2^k+1 tasks per model the partial last round costs 1/(4M+1) of the issue slots
+    // as many models per workgroup as fit ~52 KiB of LDS (three 4-wave workgroups per CU = 3 waves
+    // per SIMD), at most 8: with nfreq = 2^k+1 tasks per model the partial last round costs
+    // 1/(4M+1) of the issue slots
     size_t per = bh::rf_lds_bytes(Lmax, nsamp, 1);
-    int M = (int)((64 * 1024) / per);
+    int M = (int)((52 * 1024) / per);
     if (M > 8) M = 8;
     if (M < 1) M = 1;
     if (M > B) M = B;
@@ -144,7 +173,10 @@ int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double
     A.B = B; A.Lmax = Lmax; A.ntargets = ntargets; A.out_stride = out_stride;
     A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.periods = periods;
     A.out = out; A.err = err; A.ws = (double *)workspace;
-    BH_HIP(bh::launch_swd(A, (hipStream_t)stream));
+    int resident = 0;
+    rc = get_queue_slot(&A.counters, &resident);
+    if (rc) return rc;
+    BH_HIP(bh::launch_swd(A, resident, (hipStream_t)stream));
     return BH_OK;
 }
 

@@ -21,6 +21,7 @@ struct SwdArgs {
     double *out;
     int *err;
     double *ws;
+    unsigned int *counters;  // [BH_NT] work-queue heads, zeroed by launch_swd
     SwdTargetDev tg[BH_NT];
 };
 
@@ -33,7 +34,7 @@ struct RfArgs {
     RfLaunch P;
 };
 
-hipError_t launch_swd(const SwdArgs &A, hipStream_t stream);
+hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream);
 hipError_t launch_rf(const RfArgs &A, hipStream_t stream);
 size_t rf_lds_bytes(int Lmax, int nsamp, int M);
 

@@ -1,9 +1,10 @@
 // kernels.hip -- gfx950 kernels of libbayhunter_amd (hand-written HIP, wave64).
 //
-//   swd_kernel : one lane per (model, dispersion target); one wave per workgroup; the fp32 layer
-//                stacks of the workgroup's 64 models are staged once into LDS, layer-major
-//                ([array][layer][lane], conflict-free), from coalesced reads of the batched fp64
-//                model arrays; the search itself is swd_core.h (exact replay of surfdisp96.f).
+//   swd_kernel : persistent lanes, one (model, dispersion target) search at a time per lane, pulled
+//                from a per-target atomic work queue; one wave per workgroup; each lane keeps its
+//                current model's fp32 layer stack in its column of a layer-major LDS image
+//                ([array][layer][lane], conflict-free); the search itself is swd_core.h (exact
+//                replay of surfdisp96.f).
 //   rf_kernel  : one workgroup per M models; phases P1..P4 of rf_core.h with __syncthreads between.
 //
 // Both are fp64 scalar recurrences: bound by FP64 VALU issue + transcendental latency, not by HBM
@@ -30,47 +31,56 @@ struct LdsLay {
     __device__ __forceinline__ void set_rho(int i, float v) { base[(3 * L + i) * SWD_T] = v; }
 };
 
+// Per-target work queue: lanes pull model indices from an atomic counter (zeroed by the launcher).
+// A lane that pulls a task copies that model's fp64 row (contiguous, 32*L bytes) into ITS column of
+// the layer-major LDS image, rounding to fp32 like f2py does (surf96_modsw.py:68-82).  At kernel
+// start all 64 lanes pull together (consecutive indices -> the wave reads one contiguous chunk per
+// array); later pulls are single lanes refilling while the rest of the wave keeps searching.
+struct QueueSrc {
+    const SwdArgs &A;
+    const SwdTargetDev &tg;
+    unsigned int *counter;
+    int t;
+    long cur;
+    __device__ __forceinline__ int next(LdsLay &lay, double *&out, double *&cws, double *&cbws)
+    {
+        unsigned int b = atomicAdd(counter, 1u);
+        if (b >= (unsigned int)A.B) return 0;
+        cur = b;
+        const int L = A.Lmax;
+        int nl = A.nlay[b];
+        nl = nl < 1 ? 1 : (nl > L ? L : nl);
+        const long g = (long)b * L;
+        for (int l = 0; l < nl; l++) {
+            lay.set_d(l, (float)A.h[g + l]);
+            lay.set_a(l, (float)A.vp[g + l]);
+            lay.set_b(l, (float)A.vs[g + l]);
+            lay.set_rho(l, (float)A.rho[g + l]);
+        }
+        out = A.out + (long)b * A.out_stride + tg.out_off;
+        if (tg.mode > 1) {
+            cws = A.ws + ((long)t * 2 * BH_NP) * A.B + b;
+            cbws = cws + (long)BH_NP * A.B;
+        }
+        return nl;
+    }
+    __device__ __forceinline__ void done(int err) { A.err[cur * A.ntargets + t] = err; }
+};
+
 // 2 waves per SIMD: the search state + one Dunkin layer need ~250 VGPRs; pin the allocator there
 __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_kernel(SwdArgs A)
 {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * SWD_T;
     const int t = blockIdx.y;
-    const int L = A.Lmax;
-    const int nrows = min(SWD_T, A.B - b0);
-
-    // stage: rows b0..b0+nrows-1 of the [B][Lmax] fp64 arrays are one contiguous chunk each;
-    // read it coalesced, round to fp32 like f2py (surf96_modsw.py:68-82), store layer-major.
-    const int nelem = nrows * L;
-    const long g0 = (long)b0 * L;
-    for (int idx = tid; idx < nelem; idx += SWD_T) {
-        int r = idx / L, l = idx - r * L;
-        lds[(0 * L + l) * SWD_T + r] = (float)A.h[g0 + idx];
-        lds[(1 * L + l) * SWD_T + r] = (float)A.vp[g0 + idx];
-        lds[(2 * L + l) * SWD_T + r] = (float)A.vs[g0 + idx];
-        lds[(3 * L + l) * SWD_T + r] = (float)A.rho[g0 + idx];
-    }
-    __syncthreads();
-
-    const int b = b0 + tid;
-    if (b >= A.B) return;
     const SwdTargetDev tg = A.tg[t];
-    LdsLay lay{lds + tid, L};
-    double *cws = nullptr, *cbws = nullptr;
-    if (tg.mode > 1) {
-        cws = A.ws + ((long)t * 2 * BH_NP) * A.B + b;
-        cbws = cws + (long)BH_NP * A.B;
-    }
-    int nl = A.nlay[b];
-    nl = nl < 1 ? 1 : (nl > L ? L : nl);
-    double *out = A.out + (long)b * A.out_stride + tg.out_off;
-    int err = swd_lane(lay, nl, tg, A.periods + tg.per_off, out, cws, cbws, A.B, nullptr);
-    A.err[(long)b * A.ntargets + t] = err;
+    LdsLay lay{lds + threadIdx.x, A.Lmax};
+    QueueSrc src{A, tg, A.counters + t, t, 0};
+    swd_lane(lay, src, tg, A.periods + tg.per_off, A.B, nullptr);
 }
 
 // -------------------------------------------------------------------------------------------- RF
-__global__ __launch_bounds__(RF_T) void rf_kernel(RfArgs A)
+// 3 waves per SIMD (<= 168 VGPRs, 8 spilled dwords): the recursion is latency-bound at 2
+__global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) void rf_kernel(RfArgs A)
 {
     extern __shared__ double S[];
     const RfLaunch &P = A.P;
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(RF_T) void rf_kernel(RfArgs A)
 }
 
 // ---------------------------------------------------------------------------------------- launch
-hipError_t launch_swd(const SwdArgs &A, hipStream_t stream)
+hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
 {
     size_t lds = (size_t)4 * A.Lmax * SWD_T * sizeof(float);
     static thread_local size_t lds_set = 0;
@@ -150,8 +160,19 @@ hipError_t launch_swd(const SwdArgs &A, hipStream_t stream)
         if (e != hipSuccess) return e;
         lds_set = lds;
     }
-    dim3 grid((A.B + SWD_T - 1) / SWD_T, A.ntargets);
-    hipLaunchKernelGGL(swd_kernel, grid, dim3(SWD_T), lds, stream, A);
+    // persistent lanes: no more waves than the chip keeps resident (the queue feeds them), no more
+    // than there are models
+    // The queue pays once a lane runs >= 3 searches: it removes the 15 % lost to lanes idling until
+    // the slowest lane of their wave is done, but ends with a tail of one search length during which
+    // waves drain lane by lane ((n+0.5)T against nT/0.85).  Below that, one search per lane and as
+    // many waves as models: the hardware back-fills waves as they retire.
+    int per_target = resident_waves / A.ntargets;
+    if (per_target < 1) per_target = 1;
+    int gx = (A.B + SWD_T - 1) / SWD_T;
+    if (gx > 3 * per_target) gx = per_target;
+    hipError_t e = hipMemsetAsync(A.counters, 0, BH_NT * sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(swd_kernel, dim3(gx, A.ntargets), dim3(SWD_T), lds, stream, A);
     return hipGetLastError();
 }
 

@@ -249,6 +249,9 @@ BH_DEV void rf_phase2_interface(double *S, const RfLayout &lo, const RfLaunch &P
 }
 
 // ---- P3: one frequency of one model (greens.cpp:528-585 + compute_rf :377-395) ----------------------
+#if !defined(BH_HOSTSIM)
+#pragma clang fp contract(fast)
+#endif
 BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j)
 {
     const double *par = S + lo.off_par;
@@ -263,8 +266,8 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
         cd miwd = mk(0., -w * d);
         cd vpc = mk(1. + lgw / (BH_PI * qp), 1. / (2. * qp)) * vp;   // Mueller (1985) eq. 132
         cd vsc = mk(1. + lgw / (BH_PI * qs), 1. / (2. * qs)) * vs;
-        cd plc = csqrt_(rdiv(1., vpc * vpc) - P.p2);
-        cd slc = csqrt_(rdiv(1., vsc * vsc) - P.p2);
+        cd plc = csqrt_(crecip(vpc * vpc) - P.p2);
+        cd slc = csqrt_(crecip(vsc * vsc) - P.p2);
         cd e11 = cexp_(miwd * plc), e22 = cexp_(miwd * slc);
         const double *ci = coef + 32 * i, *cn = coef + 32 * (i + 1);
         cm2 nt;
@@ -278,7 +281,7 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
             cm2 x = ld_cm2(cn) * nb;
             x.c11 = mk(1., 0.) - x.c11; x.c12 = mk(0., 0.) - x.c12;
             x.c21 = mk(0., 0.) - x.c21; x.c22 = mk(1., 0.) - x.c22;
-            cd qi = rdiv(1., x.c11 * x.c22 - x.c12 * x.c21);
+            cd qi = crecip(x.c11 * x.c22 - x.c12 * x.c21);
             cm2 inv;
             inv.c11 = qi * x.c22; inv.c12 = (-qi) * x.c12; inv.c21 = (-qi) * x.c21; inv.c22 = qi * x.c11;
             q = inv * ld_cm2(cn + 24);
@@ -311,6 +314,10 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
     cd cq = cexp_(mk(-0.25 * (wa * wa), -w * P.tshift)) * P.qgauss;
     return crf * cq;
 }
+
+#if !defined(BH_HOSTSIM)
+#pragma clang fp contract(off)
+#endif
 
 // ---- P4: inverse FFT pieces (greens.cpp:136-158, fork.cpp:10-60) ---------------------------------------
 BH_DEV unsigned rf_bitrev(unsigned i, int log2n)

@@ -281,16 +281,21 @@ struct SwdTargetDev {
 enum { SWD_MAX_BRACKET_STEPS = 100000 };
 enum { SWD_ST_A = 0, SWD_ST_B = 1, SWD_ST_TOP = 2, SWD_ST_MID = 3, SWD_ST_DONE = 4 };
 
-// Runs one (model, target) to completion.
-//   lay      layer accessor (fp32 model, 0-based), already holding the model
-//   mmax     number of layers incl. half-space
-//   per      this target's periods (fp64)
-//   out      this (model,target)'s output slice, nper values
-//   cws/cbws per-lane c(k)/cb(k) arrays for mode > 1 (stride `wss` doubles), may be null for mode 1
-// Returns the reference's err flag.  *ncalls (optional) counts period-equation evaluations.
-template <class Lay>
-BH_DEV int swd_lane(Lay &lay, int mmax, const SwdTargetDev &tg, const double *BH_RESTRICT per,
-                    double *BH_RESTRICT out, double *cws, double *cbws, int wss, long *ncalls)
+// Runs (model, target) tasks to completion, one after the other, on this lane.
+//
+//   src      task source.  `int next(Lay &lay, double *&out, double *&cws, double *&cbws)` loads
+//            the next model of this lane's target into `lay` and returns its layer count (>= 1), or
+//            0 when the queue is drained; `void done(int err)` reports the reference's err flag of
+//            the task just finished.  On the GPU this is a per-target atomic work queue: a lane
+//            whose search ends early pulls the next model instead of idling until the slowest lane
+//            of its wave is done (searches take 388..851 period-equation evaluations on the bench
+//            models; static assignment wastes 15 % of the lane-cycles).
+//   tg       the dispersion target (same for every task of this lane), per = its periods
+//   cws/cbws per-task c(k)/cb(k) arrays for mode > 1 (stride `wss` doubles), unused for mode 1
+// *ncalls (optional) counts period-equation evaluations.
+template <class Lay, class Src>
+BH_DEV void swd_lane(Lay &lay, Src &src, const SwdTargetDev &tg, const double *BH_RESTRICT per,
+                     int wss, long *ncalls)
 {
     const double TWOPI = 2.0 * 3.141592653589793;
     const double one = 1.0e-2;
@@ -299,51 +304,61 @@ BH_DEV int swd_lane(Lay &lay, int mmax, const SwdTargetDev &tg, const double *BH
     const float h = 0.005f;
     const double pct = (double)0.01f;               // `0.01` literal in nevill is real*4
     const int ifunc = tg.iwave, igr = tg.igr, kmax = tg.nper, nmode = tg.mode;
-    int err = 0;
+    const bool multimode = nmode > 1;
     long nc = 0;
 
-    int llw = 1;
-    if (lay.b(0) <= 0.0f) llw = 2;
-    if (tg.iflsph == 1) swd_sphere(lay, mmax, ifunc);
-
-    // extremal velocities, surfdisp96.f:139-156
-    int jmn = 0, jsol = 1;
-    float betmx = -1.e20f, betmn = 1.e20f;
-    for (int i = 0; i < mmax; i++) {
-        float bi = lay.b(i), ai = lay.a(i);
-        if (bi > 0.01f && bi < betmn) { betmn = bi; jmn = i; jsol = 1; }
-        else if (bi <= 0.01f && ai < betmn) { betmn = ai; jmn = i; jsol = 0; }
-        if (bi > betmx) betmx = bi;
-    }
-    float cc1 = (jsol == 0) ? betmn : swd_gtsolh(lay.a(jmn), lay.b(jmn));
-    cc1 = .95f * cc1;
-    cc1 = .90f * cc1;
-    const double cc = (double)cc1, cm = cc;
-    const double cfail = (double)betmx + dc;        // getsol: c1 >= betmx+dc -> no root
-    const bool multimode = nmode > 1;
-    if (multimode)
-        for (int i = 0; i < kmax; i++) { cws[i * wss] = 0.0; cbws[i * wss] = 0.0; }
+    // per-task constants
+    int mmax = 1, llw = 1, err = 0;
+    float betmx = 0.f;
+    double cc = 0, cfail = 0;
+    double *out = nullptr, *cws = nullptr, *cbws = nullptr;
 
     // search state
     int iq = 1, k = 1, ift = 999, pass = 0, st = SWD_ST_DONE, ifirst = 0, idir = 1;
     int nev = 1, nctrl = 1, m = 1, nbrk = 0;
-    double t1 = 0, omega = 0, c1 = cc, c2 = 0, c3 = 0, del1 = 0, del2 = 0, del3 = 0, clow = 0,
+    double t1 = 0, omega = 0, c1 = 0, c2 = 0, c3 = 0, del1 = 0, del2 = 0, del3 = 0, clow = 0,
            del1st = 0, cprev = 0, ck = 0, ceval = 0;
     float t1a = 0, t1b = 0;
     double x1 = 0, x2 = 0, x3 = 0, x4 = 0, x5 = 0, x6 = 0, x7 = 0, x8 = 0, x9 = 0, x10 = 0, x11 = 0;
     double y1 = 0, y2 = 0, y3 = 0, y4 = 0, y5 = 0, y6 = 0, y7 = 0, y8 = 0, y9 = 0, y10 = 0, y11 = 0;
 
-    // control events raised by the search, consumed by the period/mode driver below
-    enum { EV_NONE = 0, EV_BEGIN_PERIOD, EV_SOLVED, EV_NOROOT };
-    int ev = (kmax > 0 && nmode > 0) ? EV_BEGIN_PERIOD : EV_NONE;
+    // control events raised by the search, consumed by the task/period/mode driver below
+    enum { EV_NONE = 0, EV_FETCH, EV_BEGIN_PERIOD, EV_SOLVED, EV_NOROOT };
+    int ev = EV_FETCH;
 
     for (;;) {
-        // ---------------- driver: period / pass / mode bookkeeping (surfdisp96.f:223-355) -------
+        // ---------------- driver: task / period / pass / mode bookkeeping -----------------------
         while (ev != EV_NONE) {
-            if (ev == EV_BEGIN_PERIOD) {
+            if (ev == EV_FETCH) {                     // surfdisp96.f:96-222 for the next model
+                mmax = src.next(lay, out, cws, cbws);
+                if (mmax <= 0) { st = SWD_ST_DONE; ev = EV_NONE; break; }
+                err = 0;
+                llw = 1;
+                if (lay.b(0) <= 0.0f) llw = 2;
+                if (tg.iflsph == 1) swd_sphere(lay, mmax, ifunc);
+                int jmn = 0, jsol = 1;                // extremal velocities, surfdisp96.f:139-156
+                betmx = -1.e20f;
+                float betmn = 1.e20f;
+                for (int i = 0; i < mmax; i++) {
+                    float bi = lay.b(i), ai = lay.a(i);
+                    if (bi > 0.01f && bi < betmn) { betmn = bi; jmn = i; jsol = 1; }
+                    else if (bi <= 0.01f && ai < betmn) { betmn = ai; jmn = i; jsol = 0; }
+                    if (bi > betmx) betmx = bi;
+                }
+                float cc1 = (jsol == 0) ? betmn : swd_gtsolh(lay.a(jmn), lay.b(jmn));
+                cc1 = .95f * cc1;
+                cc1 = .90f * cc1;
+                cc = (double)cc1;                     // cc = c1 = cm
+                cfail = (double)betmx + dc;           // getsol: c1 >= betmx+dc -> no root
+                if (multimode)
+                    for (int i = 0; i < kmax; i++) { cws[i * wss] = 0.0; cbws[i * wss] = 0.0; }
+                iq = 1; k = 1; ift = 999; c1 = cc;
+                if (kmax > 0 && nmode > 0) ev = EV_BEGIN_PERIOD;
+                else { src.done(err); ev = EV_FETCH; }
+            } else if (ev == EV_BEGIN_PERIOD) {
                 if (k > kmax) {                       // 1600 loop done -> next mode
                     iq++; k = 1;
-                    if (iq > nmode) { st = SWD_ST_DONE; ev = EV_NONE; break; }
+                    if (iq > nmode) { src.done(err); ev = EV_FETCH; }
                     continue;
                 }
                 if (k >= ift) { ev = EV_NOROOT; pass = 0; continue; }
@@ -365,7 +380,7 @@ BH_DEV int swd_lane(Lay &lay, int mmax, const SwdTargetDev &tg, const double *BH
                 } else {
                     ifirst = 0;
                     c1 = cprev - onea * dc;
-                    clow = cm;
+                    clow = cc;                        // clow = cm
                 }
                 pass = 0;
                 omega = TWOPI / t1;
@@ -408,8 +423,8 @@ BH_DEV int swd_lane(Lay &lay, int mmax, const SwdTargetDev &tg, const double *BH
                 ift = k;
                 for (int i = k; i <= kmax; i++) out[i - 1] = 0.0;
                 iq++; k = 1;
-                if (iq > nmode) { st = SWD_ST_DONE; ev = EV_NONE; break; }
-                ev = EV_BEGIN_PERIOD;
+                if (iq > nmode) { src.done(err); ev = EV_FETCH; }
+                else ev = EV_BEGIN_PERIOD;
             }
         }
         if (st == SWD_ST_DONE) break;
@@ -439,7 +454,7 @@ BH_DEV int swd_lane(Lay &lay, int mmax, const SwdTargetDev &tg, const double *BH
                 c1 = c2; del1 = del2;
                 // the reference leaves the scan only through these two bounds; a NaN/Inf model would
                 // spin forever there (and hang the GPU here), hence the hard step cap
-                if (c1 < cm || c1 >= cfail || ++nbrk > SWD_MAX_BRACKET_STEPS) ev = EV_NOROOT;
+                if (c1 < cc || c1 >= cfail || ++nbrk > SWD_MAX_BRACKET_STEPS) ev = EV_NOROOT;
                 else bracket_step = true;
             }
         } else {
@@ -525,8 +540,8 @@ BH_DEV int swd_lane(Lay &lay, int mmax, const SwdTargetDev &tg, const double *BH
             ev = (c1 > (double)betmx) ? EV_NOROOT : EV_SOLVED;
         }
     }
+    (void)y11;
     if (ncalls) *ncalls = nc;
-    return err;
 }
 
 }  // namespace bh

@@ -24,16 +24,36 @@ struct HostLay {
 };
 }  // namespace
 
+namespace {
+// task source of the host replay: hands out its one model once (the GPU's is an atomic queue)
+struct OneTask {
+    HostLay src;
+    int nlayer, taken = 0, err = -1;
+    double *out, *cws, *cbws;
+    int next(HostLay &lay, double *&o, double *&c, double *&cb)
+    {
+        if (taken) return 0;
+        taken = 1;
+        lay = src;
+        o = out; c = cws; cb = cbws;
+        return nlayer;
+    }
+    void done(int e) { err = e; }
+};
+}  // namespace
+
 extern "C" int hs_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
                              int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
                              const double *t, double *cg, long *ncalls)
 {
     std::vector<float> d(thkm, thkm + nlayer), a(vpm, vpm + nlayer), b(vsm, vsm + nlayer),
         r(rhom, rhom + nlayer);
-    HostLay lay{d.data(), a.data(), b.data(), r.data()};
+    HostLay lay{nullptr, nullptr, nullptr, nullptr};
     bh::SwdTargetDev tg{iwave, igr, mode, iflsph, kmax, 0, 0, 0};
     std::vector<double> cws(kmax > 0 ? kmax : 1), cbws(kmax > 0 ? kmax : 1);
-    return bh::swd_lane(lay, nlayer, tg, t, cg, cws.data(), cbws.data(), 1, ncalls);
+    OneTask src{HostLay{d.data(), a.data(), b.data(), r.data()}, nlayer, 0, -1, cg, cws.data(), cbws.data()};
+    bh::swd_lane(lay, src, tg, t, 1, ncalls);
+    return src.err;
 }
 
 namespace bh {
