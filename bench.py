@@ -38,7 +38,7 @@ F_RAYLEIGH, F_LOVE = 190.0, 30.0   # flop per layer step of the period equation 
 
 WORKLOADS = {
     #           layers        swd refs                                     periods rf    batch/GPU  cfg id
-    'joint10': dict(L=10, refs=['rdispph'], P=21, rf=True, B=131072, cfg=6),
+    'joint10': dict(L=10, refs=['rdispph'], P=21, rf=True, B=524288, cfg=6),
     'cfg2':    dict(L=5, refs=['rdispph'], P=20, rf=False, B=1024, cfg=2),
     'cfg3':    dict(L=10, refs=['rdispph', 'rdispgr', 'ldispph', 'ldispgr'], P=40, rf=False, B=8192, cfg=3),
     'cfg4':    dict(L=15, refs=['rdispph'], P=21, rf=True, B=64, cfg=4),
@@ -110,6 +110,25 @@ def cpu_baseline(wl_name, per_core=None):
                       % (n, per_core, cores, wl_name, wall)}
 
 
+def measured_traffic(kernel, workload, B):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json,
+    FETCH_SIZE doubled + WRITE_SIZE, separate --pmc runs), if one was taken at this configuration;
+    bench.py itself cannot collect PMC counters."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json'))):
+        try:
+            d = json.load(open(f))
+        except ValueError:
+            continue
+        cfg = d.get('config', '')
+        wl_ok = ('--workload ' + workload) in cfg or (workload == 'joint10' and '--workload' not in cfg)
+        b_ok = ('--batch %d' % B) in cfg or ('--batch' not in cfg and B == WORKLOADS[workload]['B'])
+        if wl_ok and b_ok and kernel in d.get('kernels', {}):
+            best = d['kernels'][kernel]['hbm_bytes']
+    return best
+
+
 def n_dltar_sample(wl):
     """Period-equation evaluations per model of the reference path (counted in the oracle, whose
     search is the reference's step for step) on 128 benchmark-seed models."""
@@ -129,8 +148,8 @@ def n_dltar_sample(wl):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='joint10', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='models per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -158,6 +177,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from bayhunter_amd.distributed import max_over_ranks
     from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
 
     torch.cuda.set_device(local_rank)
@@ -204,10 +224,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, device='cuda')
 
     ms_swd = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_rf = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if eng_rf else 0.0
@@ -224,6 +241,7 @@ def main():
         dom_bytes = (bytes_swd if dom_is_swd else bytes_rf) * B
         dom_flop = (flop_swd if dom_is_swd else flop_rf) * B
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = measured_traffic('swd_kernel' if dom_is_swd else 'rf_kernel', args.workload, B)
         value = world * B * args.steps / dt
         res = {
             "metric": "forward evals/sec (SWD+RF, 10-layer)" if args.workload == 'joint10'
@@ -240,7 +258,7 @@ def main():
                        "err_models": nerr},
             "roofline": {"kernel": "swd_kernel" if dom_is_swd else "rf_kernel", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
                          "note": "fp64 scalar recurrence: the binding limit is FP64 VALU issue + "
                                  "transcendental latency, see fp64_valu"},
