@@ -2,7 +2,6 @@
 (surface-wave dispersion + receiver functions), behind the reference's forward-plugin interface.
 """
 from ._lib import BayHunterAmdError, build, device_count, load  # noqa: F401
-from .surf96_modsw import SurfDisp  # noqa: F401
-from .rfmini_modrf import RFminiModRF  # noqa: F401
+from .plugins import RFminiModRF, SurfDisp  # noqa: F401
 
 __all__ = ['SurfDisp', 'RFminiModRF', 'build', 'load', 'device_count', 'BayHunterAmdError']

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
-SOURCES = ["kernels.hip", "capi.hip"]
+SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip"]
 HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "rf_core.h", "rf_host.h", "kernels.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
@@ -31,6 +31,15 @@ class RfParams(C.Structure):
     _fields_ = [("p", C.c_double), ("gauss", C.c_double), ("fsamp", C.c_double),
                 ("tshift", C.c_double), ("nsv", C.c_double), ("nsamp", C.c_int),
                 ("waveno", C.c_int), ("nout", C.c_int), ("out_off", C.c_int)]
+
+
+class LikeTarget(C.Structure):
+    """struct bh_like_target"""
+    _fields_ = [("n", C.c_int), ("off", C.c_int), ("cov", C.c_int), ("aux_off", C.c_int),
+                ("logdet_extra", C.c_double)]
+
+
+COV_NOCORR, COV_NOCORR_SCALED, COV_EXP, COV_GAUSS = 0, 1, 2, 3
 
 
 class BayHunterAmdError(RuntimeError):
@@ -65,11 +74,13 @@ _SIGS = {
     "bh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "bh_set_device": (C.c_int, [C.c_int]),
     "bh_swd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(SwdTarget)]),
-    "bh_swd_batch": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int,
+    "bh_swd_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                C.POINTER(SwdTarget), _vp, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "bh_rf_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(RfParams)]),
-    "bh_rf_batch": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "bh_rf_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(RfParams), _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "bh_likelihood_batch": (C.c_int, [C.c_int, C.c_int, C.POINTER(LikeTarget), _vp, C.c_int, _vp,
+                                      C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bh_surfdisp96": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, _vp, _vp, C.POINTER(C.c_int)]),
     "bh_synrf": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

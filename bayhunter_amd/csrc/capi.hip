@@ -143,12 +143,13 @@ size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets)
     return 0;
 }
 
-int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
-                 const double *vs, const double *rho, int ntargets, const bh_swd_target *targets,
-                 const double *periods, double *out, int out_stride, int *err, void *workspace,
-                 size_t workspace_bytes, void *stream)
+int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
+                 const double *vp, const double *vs, const double *rho, int ntargets,
+                 const bh_swd_target *targets, const double *periods, double *out, int out_stride,
+                 int *err, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
+    if (model_stride < Lmax) return fail_arg("model_stride < Lmax");
     if (ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("ntargets out of range");
     if (!nlay || !h || !vp || !vs || !rho || !targets || !periods || !out || !err)
         return fail_arg("NULL pointer");
@@ -170,7 +171,7 @@ int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double
         g_err = "workspace too small for mode > 1 (bh_swd_workspace_bytes)";
         return BH_ERR_WORKSPACE;
     }
-    A.B = B; A.Lmax = Lmax; A.ntargets = ntargets; A.out_stride = out_stride;
+    A.B = B; A.Lmax = Lmax; A.ntargets = ntargets; A.out_stride = out_stride; A.mstride = model_stride;
     A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.periods = periods;
     A.out = out; A.err = err; A.ws = (double *)workspace;
     int resident = 0;
@@ -182,13 +183,14 @@ int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double
 
 size_t bh_rf_workspace_bytes(int, int, const bh_rf_params *) { return 0; }
 
-static int rf_launch_common(int B, int Lmax, const int *nlay, const double *h, const double *vp,
+static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vp,
                             const double *vs, const double *rho, const double *qp, const double *qs,
                             const bh_rf_params *par, double sigma, int depth_input, double *out,
                             int out_stride, void *stream)
 {
     if (!par) return fail_arg("par is NULL");
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
+    if (model_stride < Lmax) return fail_arg("model_stride < Lmax");
     if (!nlay || !h || !vp || !vs || !rho || !out) return fail_arg("NULL pointer");
     int n = par->nsamp;
     if (n < 8 || n > 4096 || (n & (n - 1))) return fail_arg("nsamp must be a power of two in 8..4096");
@@ -211,18 +213,49 @@ static int rf_launch_common(int B, int Lmax, const int *nlay, const double *h, c
     if (bh::rf_lds_bytes(Lmax, n, 1) > 160 * 1024) return fail_arg("model does not fit LDS");
     rc = get_twiddles(n, &A.tw);
     if (rc) return rc;
-    A.B = B; A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.qp = qp; A.qs = qs;
+    A.B = B; A.mstride = model_stride; A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.qp = qp; A.qs = qs;
     A.out = out;
     BH_HIP(bh::launch_rf(A, (hipStream_t)stream));
     return BH_OK;
 }
 
-int bh_rf_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
-                const double *vs, const double *rho, const double *qp, const double *qs,
-                const bh_rf_params *par, double *out, int out_stride, void *, size_t, void *stream)
+int bh_rf_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
+                const double *vp, const double *vs, const double *rho, const double *qp,
+                const double *qs, const bh_rf_params *par, double *out, int out_stride, void *, size_t,
+                void *stream)
 {
-    return rf_launch_common(B, Lmax, nlay, h, vp, vs, rho, qp, qs, par, std::nan(""), 0, out,
-                            out_stride, stream);
+    return rf_launch_common(B, Lmax, model_stride, nlay, h, vp, vs, rho, qp, qs, par, std::nan(""), 0,
+                            out, out_stride, stream);
+}
+
+int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, const double *out,
+                        int out_stride, const int *err, int nflags, const double *yobs,
+                        const double *noise, const double *aux, double *logL, double *misfits,
+                        void *stream)
+{
+    if (B < 0 || ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("B/ntargets out of range");
+    if (!targets || !out || !yobs || !noise || !logL || !misfits) return fail_arg("NULL pointer");
+    if (nflags < 0 || (nflags > 0 && !err)) return fail_arg("err is NULL but nflags > 0");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return BH_OK;
+    bh::LikeArgs A;
+    std::memset(&A, 0, sizeof(A));
+    int nmax = 1;
+    for (int t = 0; t < ntargets; t++) {
+        const bh_like_target &s = targets[t];
+        if (s.n < 1 || s.n > bh::LIKE_NMAX) return fail_arg("target size out of range (1..1024)");
+        if (s.off < 0 || s.off + s.n > out_stride) return fail_arg("target does not fit the output row");
+        if (s.cov < 0 || s.cov > 3) return fail_arg("unknown covariance model");
+        if ((s.cov == BH_COV_NOCORR_SCALED || s.cov == BH_COV_GAUSS) && !aux) return fail_arg("aux is NULL");
+        A.tg[t] = bh::LikeTargetDev{s.n, s.off, s.cov, s.aux_off, s.logdet_extra};
+        if (s.n > nmax) nmax = s.n;
+    }
+    A.B = B; A.ntargets = ntargets; A.out_stride = out_stride; A.nflags = nflags;
+    A.out = out; A.err = err; A.yobs = yobs; A.noise = noise; A.aux = aux;
+    A.logL = logL; A.misfits = misfits;
+    BH_HIP(bh::launch_like(A, nmax, (hipStream_t)stream));
+    return BH_OK;
 }
 
 // ---- single-model drop-ins ------------------------------------------------------------------
@@ -271,7 +304,7 @@ int bh_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const f
     BH_HIP(hipMemcpy(d + off_int, ints, sizeof(ints), hipMemcpyHostToDevice));
     bh_swd_target tg = {iwave, igr, mode, iflsph, kmax, 0, 0, 0};
     const double *dm = (const double *)d;
-    rc = bh_swd_batch(1, L, (const int *)(d + off_int), dm, dm + L, dm + 2 * L, dm + 3 * L, 1, &tg,
+    rc = bh_swd_batch(1, L, L, (const int *)(d + off_int), dm, dm + L, dm + 2 * L, dm + 3 * L, 1, &tg,
                       dm + 4 * L, (double *)(d + off_out), BH_MAX_PERIODS, (int *)(d + off_int) + 1,
                       d + off_ws, 2 * BH_MAX_PERIODS * sizeof(double), nullptr);
     if (rc) return rc;
@@ -311,7 +344,7 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
     par.p = p; par.gauss = a; par.fsamp = fsamp; par.tshift = tshift; par.nsv = nsv;
     par.nsamp = nsamp; par.waveno = waveno; par.nout = nsamp; par.out_off = 0;
     const double *dm = (const double *)d;
-    rc = rf_launch_common(1, L, (const int *)(d + off_int), dm, dm + L, dm + 2 * L, dm + 3 * L,
+    rc = rf_launch_common(1, L, L, (const int *)(d + off_int), dm, dm + L, dm + 2 * L, dm + 3 * L,
                           dm + 4 * L, dm + 5 * L, &par, sigma, 1, (double *)(d + off_out), nsamp, nullptr);
     if (rc) return rc;
     BH_HIP(hipDeviceSynchronize());

@@ -15,6 +15,7 @@ constexpr int BH_NT = 16;   // BH_MAX_TARGETS
 
 struct SwdArgs {
     int B, Lmax, ntargets, out_stride;
+    int mstride;             // elements between consecutive models in h/vp/vs/rho
     const int *nlay;
     const double *h, *vp, *vs, *rho;
     const double *periods;
@@ -27,6 +28,7 @@ struct SwdArgs {
 
 struct RfArgs {
     int B;
+    int mstride;             // elements between consecutive models in h/vp/vs/rho
     const int *nlay;
     const double *h, *vp, *vs, *rho, *qp, *qs;
     const double *tw;  // FFT twiddles, rf_host.h
@@ -34,6 +36,24 @@ struct RfArgs {
     RfLaunch P;
 };
 
+struct LikeTargetDev {
+    int n, off, cov, aux_off;
+    double logdet_extra;
+};
+constexpr int LIKE_T = 256;   // threads per workgroup
+constexpr int LIKE_M = 8;     // models per workgroup (register tile of the dense R^-1 product)
+constexpr int LIKE_NMAX = 1024;  // max data points per target (LDS: LIKE_M*n doubles)
+
+struct LikeArgs {
+    int B, ntargets, out_stride, nflags;
+    const double *out;
+    const int *err;
+    const double *yobs, *noise, *aux;
+    double *logL, *misfits;
+    LikeTargetDev tg[BH_NT];
+};
+
+hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream);
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream);
 hipError_t launch_rf(const RfArgs &A, hipStream_t stream);
 size_t rf_lds_bytes(int Lmax, int nsamp, int M);

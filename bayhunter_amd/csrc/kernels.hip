@@ -50,7 +50,7 @@ struct QueueSrc {
         const int L = A.Lmax;
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
-        const long g = (long)b * L;
+        const long g = (long)b * A.mstride;
         for (int l = 0; l < nl; l++) {
             lay.set_d(l, (float)A.h[g + l]);
             lay.set_a(l, (float)A.vp[g + l]);
@@ -98,8 +98,9 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         if (i < nl)
-            rf_phase1_layer(S + (long)m * lo.per_model, lo, nl, i, A.h + b * L, A.vp + b * L,
-                            A.vs + b * L, A.rho + b * L, A.qp ? A.qp + b * L : nullptr,
+            rf_phase1_layer(S + (long)m * lo.per_model, lo, nl, i, A.h + b * A.mstride,
+                            A.vp + b * A.mstride, A.vs + b * A.mstride, A.rho + b * A.mstride,
+                            A.qp ? A.qp + b * L : nullptr,
                             A.qs ? A.qs + b * L : nullptr, P.depth_input);
     }
     __syncthreads();
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         if (i < nl)
-            rf_phase2_interface(S + (long)m * lo.per_model, lo, P, nl, i, A.vp[b * L], A.vs[b * L]);
+            rf_phase2_interface(S + (long)m * lo.per_model, lo, P, nl, i, A.vp[b * A.mstride],
+                                A.vs[b * A.mstride]);
     }
     __syncthreads();
     // P3: (model, frequency) tasks, model-major

@@ -1,0 +1,169 @@
+// like_kernel.hip -- fused misfit + Gaussian log-likelihood for a batch of models.
+//
+// Reference: JointTarget.evaluate, src/Targets.py:322-347, with the covariance models of
+// Valuation (src/Targets.py:105-173).  The reference materialises a dense n x n inverse covariance
+// for every evaluation and does two numpy dots; here the diagonal and exponential (tridiagonal)
+// models are closed-form single passes and only the fixed Gaussian model multiplies by a dense
+// matrix: R^-1 (n x n, fixed for the whole run) is streamed once per workgroup from L2 while LIKE_M
+// models' residual vectors sit in LDS, i.e. every matrix element fetched is used LIKE_M times.
+//
+// One workgroup = LIKE_M models, LIKE_T threads.  HBM traffic: the model's output row is read once
+// (it is what swd_kernel/rf_kernel just wrote), 8*(ntargets+2) bytes are written per model.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace bh {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(LIKE_T) void like_kernel(LikeArgs A)
+{
+    extern __shared__ double sm[];          // [LIKE_M][nmax] residuals, then [LIKE_M][4] partials
+    __shared__ double red[LIKE_M][LIKE_T / 64][2];
+    __shared__ double acc_logl[LIKE_M];
+    __shared__ double acc_mis[LIKE_M];
+    __shared__ int bad[LIKE_M];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b0 = blockIdx.x * LIKE_M;
+    const int Mb = min(LIKE_M, A.B - b0);
+    const int NW = LIKE_T / 64;
+
+    if (tid < LIKE_M) {
+        acc_logl[tid] = 0.0;
+        acc_mis[tid] = 0.0;
+        int flag = 0;
+        if (tid < Mb)
+            for (int f = 0; f < A.nflags; f++) flag |= A.err[(long)(b0 + tid) * A.nflags + f];
+        bad[tid] = flag;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < A.ntargets; t++) {
+        const LikeTargetDev tg = A.tg[t];
+        const int n = tg.n;
+        // residuals d = ymod - yobs of the workgroup's models -> LDS (coalesced row reads)
+        for (int idx = tid; idx < Mb * n; idx += LIKE_T) {
+            int m = idx / n, i = idx - m * n;
+            sm[m * n + i] = A.out[(long)(b0 + m) * A.out_stride + tg.off + i] - A.yobs[tg.off + i];
+        }
+        __syncthreads();
+
+        if (tg.cov == 3) {
+            // q_m = d_m^T R^-1 d_m : thread i owns row i for all LIKE_M models
+            const double *R = A.aux + tg.aux_off;
+            double s2[LIKE_M], q[LIKE_M];
+#pragma unroll
+            for (int m = 0; m < LIKE_M; m++) { s2[m] = 0.0; q[m] = 0.0; }
+            for (int i = tid; i < n; i += LIKE_T) {
+                double rd[LIKE_M];
+#pragma unroll
+                for (int m = 0; m < LIKE_M; m++) rd[m] = 0.0;
+                const double *Ri = R + (long)i * n;
+                for (int j = 0; j < n; j++) {
+                    double r = Ri[j];
+#pragma unroll
+                    for (int m = 0; m < LIKE_M; m++) rd[m] += r * sm[m * n + j];
+                }
+#pragma unroll
+                for (int m = 0; m < LIKE_M; m++) {
+                    double d = sm[m * n + i];
+                    q[m] += d * rd[m];
+                    s2[m] += d * d;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < LIKE_M; m++) {
+                double a = wave_sum(s2[m]), c = wave_sum(q[m]);
+                if (lane == 0) { red[m][wv][0] = a; red[m][wv][1] = c; }
+            }
+        } else {
+            // closed forms: wave w handles models w, w+NW, ...
+            for (int m = wv; m < LIKE_M; m += NW) {
+                double s2 = 0.0, q = 0.0;
+                if (m < Mb) {
+                    const double *d = sm + m * n;
+                    if (tg.cov == 0) {
+                        for (int i = lane; i < n; i += 64) s2 += d[i] * d[i];
+                        q = s2;
+                    } else if (tg.cov == 1) {
+                        const double *se = A.aux + tg.aux_off;
+                        for (int i = lane; i < n; i += 64) {
+                            double dd = d[i] * d[i];
+                            s2 += dd;
+                            q += dd / se[i];
+                        }
+                    } else {   // exponential law: R^-1 tridiagonal, src/Targets.py:130-137
+                        double r = A.noise[(long)(b0 + m) * 2 * A.ntargets + 2 * t];
+                        for (int i = lane; i < n; i += 64) {
+                            double dd = d[i] * d[i];
+                            s2 += dd;
+                            double diag = (i == 0 || i == n - 1) ? 1.0 : 1.0 + r * r;
+                            q += diag * dd;
+                            if (i + 1 < n) q -= 2.0 * r * d[i] * d[i + 1];
+                        }
+                    }
+                }
+                s2 = wave_sum(s2);
+                q = wave_sum(q);
+                if (lane == 0) {
+                    for (int w = 0; w < NW; w++) { red[m][w][0] = 0.0; red[m][w][1] = 0.0; }
+                    red[m][0][0] = s2;
+                    red[m][0][1] = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < Mb) {
+            const int m = tid;
+            double s2 = 0.0, q = 0.0;
+            for (int w = 0; w < NW; w++) { s2 += red[m][w][0]; q += red[m][w][1]; }
+            const double corr = A.noise[(long)(b0 + m) * 2 * A.ntargets + 2 * t];
+            const double sigma = A.noise[(long)(b0 + m) * 2 * A.ntargets + 2 * t + 1];
+            double madist, logdet = (2.0 * n) * log(sigma);
+            if (tg.cov == 2) {
+                madist = q / (sigma * sigma * (1.0 - corr * corr));
+                logdet += (n - 1) * log(1.0 - corr * corr);
+            } else {
+                madist = q / (sigma * sigma);
+                logdet += tg.logdet_extra;
+            }
+            const double logl_part = -0.5 * (n * log(2.0 * 3.141592653589793) + logdet);
+            acc_logl[m] += logl_part - madist / 2.0;
+            const double rms = sqrt(s2 / n);
+            acc_mis[m] += rms;
+            A.misfits[(long)(b0 + m) * (A.ntargets + 1) + t] = bad[m] ? 1e15 : rms;
+        }
+        __syncthreads();
+    }
+    if (tid < Mb) {
+        const int m = tid;
+        if (bad[m]) {   // src/Targets.py:325-328
+            A.logL[b0 + m] = -1e15;
+            for (int t = 0; t <= A.ntargets; t++) A.misfits[(long)(b0 + m) * (A.ntargets + 1) + t] = 1e15;
+        } else {
+            A.logL[b0 + m] = acc_logl[m];
+            A.misfits[(long)(b0 + m) * (A.ntargets + 1) + A.ntargets] = acc_mis[m];
+        }
+    }
+}
+
+hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
+{
+    size_t lds = (size_t)LIKE_M * nmax * sizeof(double);
+    static thread_local size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)like_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    dim3 grid((A.B + LIKE_M - 1) / LIKE_M);
+    hipLaunchKernelGGL(like_kernel, grid, dim3(LIKE_T), lds, stream, A);
+    return hipGetLastError();
+}
+
+}  // namespace bh

@@ -1,7 +1,7 @@
 """Batched forward engine: many layered models per launch, inputs and outputs resident in HBM.
 
 This is the entry point the reference does not have (it evaluates one model per call,
-src/Targets.py:314-347); the single-model plugin classes in surf96_modsw.py / rfmini_modrf.py are
+src/Targets.py:314-347); the single-model plugin classes in plugins.py are
 thin views on it.  torch is used only for device memory and streams.
 """
 import ctypes as C
@@ -18,21 +18,18 @@ RF_REFS = {'prf': 0, 'seis': 0, 'srf': 1}
 def rf_obsparams(obsx, ref='prf'):
     """fsamp, tshft, nsamp from the observed time axis (src/rfmini_modrf.py:41-62)."""
     obsx = np.asarray(obsx, dtype=np.float64)
-    deltas = np.round((obsx[1:] - obsx[:-1]), 4)
-    if np.unique(deltas).size == 1:
-        dt = float(deltas[0])
-        fsamp = 1. / dt
-    else:
-        raise ValueError("Target: %s. Sampling rate must be constant." % ref)
-    tshft = -obsx[0]
-    nsamp = 2.**int(np.ceil(np.log2(obsx.size * 2)))
-    return fsamp, float(tshft), nsamp
+    steps = np.unique(np.round(np.diff(obsx), 4))
+    if steps.size != 1:
+        raise ValueError("receiver-function target '%s': the time axis must be uniformly sampled" % ref)
+    fsamp = 1. / float(steps[0])
+    nsamp = 2.**int(np.ceil(np.log2(obsx.size * 2)))       # a float, like the reference's
+    return fsamp, float(-obsx[0]), nsamp
 
 
 class SwdSpec(object):
     def __init__(self, ref, periods, mode=1, flsph=0):
         if ref not in SWD_REFS:
-            raise ReferenceError("Reference is not available in SurfDisp: %s" % ref)
+            raise ReferenceError("no dispersion forward model for ref '%s'" % ref)
         self.ref = ref
         self.iwave, self.igr = SWD_REFS[ref]
         self.periods = np.ascontiguousarray(periods, dtype=np.float64)
@@ -43,11 +40,14 @@ class SwdSpec(object):
 
 
 class RfSpec(object):
-    def __init__(self, ref, obsx, gauss=1.0, p=6.4, nsv=None):
-        if ref not in RF_REFS:
-            raise ReferenceError("Reference is not available in RFminiModRF: %s" % ref)
+    def __init__(self, ref, obsx, gauss=1.0, p=6.4, nsv=None, wtype=None):
+        if wtype is None:
+            if ref not in RF_REFS:
+                raise ReferenceError("no receiver-function forward model for ref '%s'" % ref)
+            self.waveno = RF_REFS[ref]
+        else:
+            self.waveno = {'P': 0, 'SV': 1}[wtype]
         self.ref = ref
-        self.waveno = RF_REFS[ref]
         self.obsx = np.ascontiguousarray(obsx, dtype=np.float64)
         self.fsamp, self.tshft, self.nsamp = rf_obsparams(self.obsx, ref)
         self.gauss, self.p, self.nsv = float(gauss), float(p), nsv
@@ -104,10 +104,18 @@ class ForwardEngine(object):
         return torch.from_numpy(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
 
     def upload(self, H, VP, VS, RHO, nlay):
-        """Host arrays [B, Lmax] (+ int nlay[B]) -> device tensors."""
+        """[B, Lmax] arrays (+ int nlay[B]) -> device tensors in the packed [B, 4, Lmax] layout:
+        one contiguous 32*Lmax-byte block per model, which is what a lane fetches from the work
+        queue.  Returns views (H, VP, VS, RHO, nlay); views of an already packed tensor pass through."""
         f64 = torch.float64
-        return (self._as_dev(H, f64), self._as_dev(VP, f64), self._as_dev(VS, f64),
-                self._as_dev(RHO, f64), self._as_dev(nlay, torch.int32))
+        if isinstance(H, torch.Tensor) and getattr(H, '_bh_packed', None) is not None:
+            return H, VP, VS, RHO, self._as_dev(nlay, torch.int32)
+        parts = [self._as_dev(x, f64) for x in (H, VP, VS, RHO)]
+        packed = torch.stack(parts, dim=1).contiguous()
+        views = [packed[:, i, :] for i in range(4)]
+        for v in views:
+            v._bh_packed = packed
+        return views[0], views[1], views[2], views[3], self._as_dev(nlay, torch.int32)
 
     def alloc_out(self, B):
         out = torch.empty((B, self.row), dtype=torch.float64, device=self.device)
@@ -118,6 +126,7 @@ class ForwardEngine(object):
         """Launch all targets for the batch (asynchronous).  Returns (out[B,row], err[B,nswd])."""
         H, VP, VS, RHO, nlay = self.upload(H, VP, VS, RHO, nlay)
         B, Lmax = H.shape
+        mstride = H.stride(0)
         if out is None or err is None:
             out, err = self.alloc_out(B)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
@@ -131,13 +140,13 @@ class ForwardEngine(object):
                         self._ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
                     ws_ptr = self._ws.data_ptr()
                 _lib.check(self.lib.bh_swd_batch(
-                    B, Lmax, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
+                    B, Lmax, mstride, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
                     RHO.data_ptr(), len(self.swd), self._tg, self.periods.data_ptr(),
                     out.data_ptr(), self.row, err.data_ptr(), ws_ptr, need, sp))
             else:
                 err.zero_()
             for rp in self._rfp:
                 _lib.check(self.lib.bh_rf_batch(
-                    B, Lmax, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
+                    B, Lmax, mstride, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
                     RHO.data_ptr(), None, None, C.byref(rp), out.data_ptr(), self.row, None, 0, sp))
         return out, err

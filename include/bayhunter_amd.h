@@ -74,15 +74,20 @@ int  bh_device_count(int *count);
 int  bh_set_device(int device);
 
 /* ---- batched surface-wave dispersion (device pointers) ---------------------------------- */
-/* Models: fp64 row-major [B][Lmax] arrays h, vp, vs, rho and int32 nlay[B] (layers incl. the
- * half-space, 1 <= nlay <= Lmax <= BH_MAX_LAYERS).  They are rounded to fp32 on load exactly like
- * f2py does for the reference (surf96_modsw.py:68-82).  `targets` is a HOST array.
+/* Models: fp64 arrays h, vp, vs, rho holding Lmax values per model, model b at element offset
+ * b*model_stride of each pointer, and int32 nlay[B] (layers incl. the half-space,
+ * 1 <= nlay <= Lmax <= BH_MAX_LAYERS).  model_stride = Lmax for four separate row-major [B][Lmax]
+ * arrays; model_stride = 4*Lmax with vp = h+Lmax, vs = h+2*Lmax, rho = h+3*Lmax for the packed
+ * [B][4][Lmax] layout (one contiguous 32*Lmax-byte block per model: what a lane fetches when it
+ * pulls a model from the work queue).  Values are rounded to fp32 on load exactly like f2py does
+ * for the reference (surf96_modsw.py:68-82).  `targets` is a HOST array.
  * out[b*out_stride + out_off + k], k < nper: phase/group velocity; failed and later periods are 0.
  * err[b*ntargets + t]: the reference's err flag for that (model, target).
  * workspace: only needed when some target has mode > 1 (bh_swd_workspace_bytes). */
 size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets);
-int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
-                 const double *vs, const double *rho, int ntargets, const bh_swd_target *targets,
+int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
+                 const double *vp, const double *vs, const double *rho, int ntargets,
+                 const bh_swd_target *targets,
                  const double *periods, double *out, int out_stride, int *err,
                  void *workspace, size_t workspace_bytes, void *stream);
 
@@ -90,10 +95,38 @@ int bh_swd_batch(int B, int Lmax, const int *nlay, const double *h, const double
 /* qp/qs may be NULL: 500 / 225 like rfmini_modrf.py:119-120.  Output: the first nout samples of
  * the RF trace at out[b*out_stride + out_off + i].  NaN propagates like in the reference. */
 size_t bh_rf_workspace_bytes(int B, int Lmax, const bh_rf_params *par);
-int bh_rf_batch(int B, int Lmax, const int *nlay, const double *h, const double *vp,
-                const double *vs, const double *rho, const double *qp, const double *qs,
+int bh_rf_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
+                const double *vp, const double *vs, const double *rho, const double *qp,
+                const double *qs, /* qp/qs: [B][Lmax] (stride Lmax) or NULL */
                 const bh_rf_params *par, double *out, int out_stride,
                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- fused likelihood (device pointers) ------------------------------------------------- */
+/* JointTarget.evaluate's tail (src/Targets.py:322-347) for a batch: per target RMS misfit and
+ * Gaussian log-likelihood with one of the four covariance models of Valuation
+ * (src/Targets.py:105-173), summed over targets.  Consumes the output rows of bh_swd_batch /
+ * bh_rf_batch in place.  Per model b:
+ *   logL[b]                      sum over targets of -0.5*(n*log(2*pi) + logdet) - madist/2
+ *   misfits[b*(ntargets+1) + t]  RMS of target t;  [.. + ntargets] their sum
+ * A model with a non-zero err flag in any of its flag columns gets logL = -1e15 and all misfits
+ * 1e15 (src/Targets.py:325-328); NaN data propagates exactly like in the reference. */
+#define BH_COV_NOCORR        0 /* get_covariance_nocorr            C^-1 = I/sigma^2                   */
+#define BH_COV_NOCORR_SCALED 1 /* get_covariance_nocorr_scalederr  C^-1 = diag(1/(scaled_err*sigma^2)) */
+#define BH_COV_EXP           2 /* get_covariance_exp               tridiagonal closed form             */
+#define BH_COV_GAUSS         3 /* get_covariance_gauss             fixed dense R^-1 / sigma^2          */
+typedef struct bh_like_target {
+    int    n;        /* number of data points                                                  */
+    int    off;      /* first column of the target in the output row (= offset in yobs too)    */
+    int    cov;      /* BH_COV_*                                                               */
+    int    aux_off;  /* element offset in `aux`: scaled_err[n] (SCALED) or R^-1[n*n] row-major (GAUSS) */
+    double logdet_extra; /* SCALED: log(prod(scaled_err)); GAUSS: log det R; else 0           */
+} bh_like_target;
+/* yobs: observed data laid out like an output row [row_len]; noise: [B][2*ntargets] (corr, sigma)
+ * pairs per target (src/Targets.py:338); err: [B][nflags] int32 flags (may be NULL with nflags 0). */
+int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, const double *out,
+                        int out_stride, const int *err, int nflags, const double *yobs,
+                        const double *noise, const double *aux, double *logL, double *misfits,
+                        void *stream);
 
 /* ---- single-model drop-ins (host pointers, synchronous) --------------------------------- */
 /* Same argument list as the f2py wrapper of `subroutine surfdisp96`; model arrays are real*4 with

@@ -53,8 +53,11 @@ def test_product_never_touches_oracle():
 def test_arg_validation_without_gpu(lib):
     from bayhunter_amd import _lib
     import ctypes as C
-    tg = (_lib.SwdTarget * 1)(_lib.SwdTarget(3, 0, 1, 0, 21, 0, 0, 0))
-    rc = lib.bh_swd_batch(4, 101, 1, 1, 1, 1, 1, 1, tg, 1, 1, 21, 1, None, 0, None)
+    tg = (_lib.SwdTarget * 1)(_lib.SwdTarget(3, 0, 1, 0, 21, 0, 0, 0))   # iwave 3 is invalid
+    rc = lib.bh_swd_batch(4, 101, 101, 1, 1, 1, 1, 1, 1, tg, 1, 1, 21, 1, None, 0, None)
+    assert rc == _lib.BH_ERR_ARG
+    tg[0].iwave = 2
+    rc = lib.bh_swd_batch(4, 10, 9, 1, 1, 1, 1, 1, 1, tg, 1, 1, 21, 1, None, 0, None)   # stride < Lmax
     assert rc == _lib.BH_ERR_ARG
     assert lib.bh_swd_workspace_bytes(100, 1, tg) == 0
     tg[0].mode = 2
