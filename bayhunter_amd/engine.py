@@ -94,6 +94,8 @@ class ForwardEngine(object):
             self.periods = torch.from_numpy(
                 np.concatenate(pers) if pers else np.zeros(1)).to(self.device)
         self._ws = None
+        self._side = None        # side stream: RF back-fills the SIMDs the SWD tail leaves idle
+        self.overlap = True
 
     # -- helpers
     def _as_dev(self, x, dtype):
@@ -132,6 +134,15 @@ class ForwardEngine(object):
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         sp = C.c_void_p(st.cuda_stream)
         with torch.cuda.device(self.device):
+            # The two kernels are independent.  swd_kernel ends with a tail in which its persistent
+            # waves retire one by one; launched on a second stream, rf_kernel's workgroups take over
+            # the freed SIMDs instead of waiting for the last search to finish.
+            side = None
+            if self.swd and self._rfp and self.overlap:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                side = self._side
+                side.wait_stream(st)
             if self.swd:
                 need = self.lib.bh_swd_workspace_bytes(B, len(self.swd), self._tg)
                 ws_ptr = None
@@ -145,8 +156,13 @@ class ForwardEngine(object):
                     out.data_ptr(), self.row, err.data_ptr(), ws_ptr, need, sp))
             else:
                 err.zero_()
+            rsp = sp if side is None else C.c_void_p(side.cuda_stream)
             for rp in self._rfp:
                 _lib.check(self.lib.bh_rf_batch(
                     B, Lmax, mstride, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
-                    RHO.data_ptr(), None, None, C.byref(rp), out.data_ptr(), self.row, None, 0, sp))
+                    RHO.data_ptr(), None, None, C.byref(rp), out.data_ptr(), self.row, None, 0, rsp))
+            if side is not None:
+                st.wait_stream(side)
+                for t in (H, VP, VS, RHO, nlay, out):
+                    t.record_stream(side)
         return out, err
