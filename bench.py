@@ -180,10 +180,13 @@ def main():
     from bayhunter_amd.distributed import max_over_ranks
     from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
 
-    torch.cuda.set_device(local_rank)
+    # BH_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 code path on a
+    # one-GPU box (ranks then share device 0); the driver runs one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get('BH_DIST_BACKEND', 'nccl')
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        dist.init_process_group(backend)
 
     B = args.batch or wl['B']
     per = np.linspace(1, 41, wl['P'])
@@ -217,7 +220,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt, device='cuda')
+    dt = max_over_ranks(dt, device='cuda' if backend == 'nccl' else 'cpu')
 
     # per-kernel durations for the roofline: the same launches, serialised on one stream, bracketed
     # by events on that stream (in the timed steps above rf_kernel overlaps the tail of swd_kernel)
