@@ -39,6 +39,14 @@ class LikeTarget(C.Structure):
                 ("logdet_extra", C.c_double)]
 
 
+class ModelPriors(C.Structure):
+    """struct bh_model_priors"""
+    _fields_ = [("layers_min", C.c_int), ("layers_max", C.c_int), ("vs_min", C.c_double),
+                ("vs_max", C.c_double), ("z_min", C.c_double), ("z_max", C.c_double),
+                ("thickmin", C.c_double), ("lowvelperc", C.c_double), ("highvelperc", C.c_double),
+                ("mantle_vs", C.c_double), ("mantle_vpvs", C.c_double)]
+
+
 COV_NOCORR, COV_NOCORR_SCALED, COV_EXP, COV_GAUSS = 0, 1, 2, 3
 
 
@@ -79,6 +87,8 @@ _SIGS = {
     "bh_rf_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(RfParams)]),
     "bh_rf_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(RfParams), _vp, C.c_int, _vp, C.c_size_t, _vp]),
+    "bh_voronoi_to_layers": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(ModelPriors),
+                                       _vp, _vp, _vp]),
     "bh_likelihood_batch": (C.c_int, [C.c_int, C.c_int, C.POINTER(LikeTarget), _vp, C.c_int, _vp,
                                       C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bh_surfdisp96": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -228,6 +228,25 @@ int bh_rf_batch(int B, int Lmax, int model_stride, const int *nlay, const double
                             out, out_stride, stream);
 }
 
+int bh_voronoi_to_layers(int B, int Lmax, const int *nlay, const double *vs_nuclei,
+                         const double *z_nuclei, const double *vpvs, const bh_model_priors *pri,
+                         double *model, int *valid, void *stream)
+{
+    if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
+    if (!nlay || !vs_nuclei || !z_nuclei || !vpvs || !pri || !model || !valid) return fail_arg("NULL pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (B == 0) return BH_OK;
+    bh::VoronoiArgs A;
+    A.B = B; A.Lmax = Lmax; A.nlay = nlay; A.vs = vs_nuclei; A.z = z_nuclei; A.vpvs = vpvs;
+    A.model = model; A.valid = valid;
+    A.pri = bh::ModelPriorsDev{pri->layers_min, pri->layers_max, pri->vs_min, pri->vs_max, pri->z_min,
+                               pri->z_max, pri->thickmin, pri->lowvelperc, pri->highvelperc,
+                               pri->mantle_vs, pri->mantle_vpvs};
+    BH_HIP(bh::launch_voronoi(A, (hipStream_t)stream));
+    return BH_OK;
+}
+
 int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, const double *out,
                         int out_stride, const int *err, int nflags, const double *yobs,
                         const double *noise, const double *aux, double *logL, double *misfits,

@@ -36,6 +36,20 @@ struct RfArgs {
     RfLaunch P;
 };
 
+struct ModelPriorsDev {
+    int layers_min, layers_max;
+    double vs_min, vs_max, z_min, z_max, thickmin, lowvelperc, highvelperc, mantle_vs, mantle_vpvs;
+};
+struct VoronoiArgs {
+    int B, Lmax;
+    const int *nlay;
+    const double *vs, *z, *vpvs;
+    double *model;
+    int *valid;
+    ModelPriorsDev pri;
+};
+hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream);
+
 struct LikeTargetDev {
     int n, off, cov, aux_off;
     double logdet_extra;

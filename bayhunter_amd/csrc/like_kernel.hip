@@ -151,6 +151,57 @@ __global__ __launch_bounds__(LIKE_T) void like_kernel(LikeArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Voronoi nuclei -> layers (src/Models.py:26-52) + prior checks (src/SingleChain.py:330-392).
+// One lane per proposal; every operation is the reference's IEEE operation, so h, vp, rho are
+// bit-identical to numpy's.  Byte-bound and tiny: 16*L bytes in, 32*L out per model.
+__global__ __launch_bounds__(256) void voronoi_kernel(VoronoiArgs A)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.B) return;
+    const int L = A.Lmax;
+    const ModelPriorsDev &P = A.pri;
+    int n = A.nlay[b];
+    n = n < 1 ? 1 : (n > L ? L : n);
+    const double *vs = A.vs + (long)b * L, *z = A.z + (long)b * L;
+    double *mh = A.model + (long)b * 4 * L, *mvp = mh + L, *mvs = mh + 2 * L, *mrho = mh + 3 * L;
+    const double vpvs = A.vpvs[b];
+    const bool mantle = P.mantle_vs == P.mantle_vs;
+    bool ok = true, in_mantle = false;
+    const int layermodel = n - 1;
+    if (!(layermodel >= P.layers_min && layermodel <= P.layers_max)) ok = false;
+    double zprev = 0.0, zsum = 0.0, vsprev = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double v = vs[i];
+        double h = 0.0;
+        if (i < n - 1) {
+            const double zd = (z[i] + z[i + 1]) / 2.;       // interface midway between nuclei
+            h = zd - zprev;
+            zprev = zd;
+            if (h < P.thickmin) ok = false;
+        }
+        zsum = zsum + h;                                     // np.cumsum(h)
+        if (zsum < P.z_min || zsum > P.z_max) ok = false;
+        if (v < P.vs_min || v > P.vs_max) ok = false;
+        if (mantle && v >= P.mantle_vs) in_mantle = true;    // from the first mantle layer downwards
+        const double vp = in_mantle ? v * P.mantle_vpvs : v * vpvs;
+        if (i > 0) {
+            if (P.lowvelperc == P.lowvelperc && !((v - (vsprev * (1 - P.lowvelperc))) > 0)) ok = false;
+            if (P.highvelperc == P.highvelperc && !(((vsprev * (1 + P.highvelperc)) - v) > 0)) ok = false;
+        }
+        vsprev = v;
+        mh[i] = h; mvp[i] = vp; mvs[i] = v; mrho[i] = vp * 0.32 + 0.77;
+    }
+    for (int i = n; i < L; i++) { mh[i] = 0.0; mvp[i] = 0.0; mvs[i] = 0.0; mrho[i] = 0.0; }
+    A.valid[b] = ok ? 1 : 0;
+}
+
+hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream)
+{
+    hipLaunchKernelGGL(voronoi_kernel, dim3((A.B + 255) / 256), dim3(256), 0, stream, A);
+    return hipGetLastError();
+}
+
 hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
 {
     size_t lds = (size_t)LIKE_M * nmax * sizeof(double);

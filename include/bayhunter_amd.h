@@ -101,6 +101,26 @@ int bh_rf_batch(int B, int Lmax, int model_stride, const int *nlay, const double
                 const bh_rf_params *par, double *out, int out_stride,
                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Voronoi nuclei -> layered models + prior checks (device pointers) ------------------- */
+/* The step in front of the forward path: Model.get_vp_vs_h (src/Models.py:26-52) and
+ * SingleChain._validmodel (src/SingleChain.py:330-392) for a batch of proposals.  Input per model:
+ * nlay nuclei (vs[i], z_vnoi[i]) sorted by depth, rows of [B][Lmax] arrays, and the chain's vpvs.
+ * Output: the packed model block [B][4][Lmax] (h, vp, vs, rho = 0.77 + 0.32*vp, src/Targets.py:319;
+ * zero padded) that bh_swd_batch / bh_rf_batch take with model_stride = 4*Lmax, and valid[b] = 1
+ * iff the proposal passes every prior check.  NaN fields of the struct mean "None". */
+typedef struct bh_model_priors {
+    int    layers_min, layers_max; /* priors['layers'], counted without the half-space        */
+    double vs_min, vs_max;         /* priors['vs']                                             */
+    double z_min, z_max;           /* priors['z']                                              */
+    double thickmin;               /* initparams['thickmin']                                   */
+    double lowvelperc;             /* initparams['lvz'] or NaN                                 */
+    double highvelperc;            /* initparams['hvz'] or NaN                                 */
+    double mantle_vs, mantle_vpvs; /* priors['mantle'] = (vs threshold, vp/vs) or NaN, NaN     */
+} bh_model_priors;
+int bh_voronoi_to_layers(int B, int Lmax, const int *nlay, const double *vs_nuclei,
+                         const double *z_nuclei, const double *vpvs, const bh_model_priors *pri,
+                         double *model, int *valid, void *stream);
+
 /* ---- fused likelihood (device pointers) ------------------------------------------------- */
 /* JointTarget.evaluate's tail (src/Targets.py:322-347) for a batch: per target RMS misfit and
  * Gaussian log-likelihood with one of the four covariance models of Valuation
