@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
 SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip"]
-HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "rf_core.h", "rf_host.h", "kernels.h"]
+HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "swd_team.h", "rf_core.h", "rf_host.h", "kernels.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
@@ -81,6 +81,7 @@ _SIGS = {
     "bh_last_error": (C.c_char_p, []),
     "bh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "bh_set_device": (C.c_int, [C.c_int]),
+    "bh_swd_set_kernel": (C.c_int, [C.c_int]),
     "bh_swd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(SwdTarget)]),
     "bh_swd_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                C.POINTER(SwdTarget), _vp, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
@@ -127,6 +128,11 @@ def check(rc):
     if rc != BH_OK:
         msg = load().bh_last_error().decode()
         raise BayHunterAmdError("libbayhunter_amd error %d: %s" % (rc, msg))
+
+
+def set_swd_kernel(mode):
+    """'auto' | 'lane' | 'team' (include/bayhunter_amd.h, bh_swd_set_kernel)."""
+    check(load().bh_swd_set_kernel({'auto': 0, 'lane': 1, 'team': 2}[mode]))
 
 
 def device_count():

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -98,6 +99,14 @@ int get_queue_slot(unsigned int **slot, int *resident_waves)
     return BH_OK;
 }
 
+int g_swd_mode = BH_SWD_AUTO;
+
+long team_threshold()
+{
+    static const char *e = std::getenv("BH_SWD_TEAM_MAX");
+    return e ? std::atol(e) : 8192;    // measured crossover on MI355X
+}
+
 int pick_rf_M(int B, int Lmax, int nsamp)
 {
     // as many models per workgroup as fit ~52 KiB of LDS (three 4-wave workgroups per CU = 3 waves
@@ -132,6 +141,13 @@ int bh_set_device(int device)
     int rc = ensure_device();
     if (rc) return rc;
     BH_HIP(hipSetDevice(device));
+    return BH_OK;
+}
+
+int bh_swd_set_kernel(int mode)
+{
+    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM) return fail_arg("unknown kernel mode");
+    g_swd_mode = mode;
     return BH_OK;
 }
 
@@ -177,7 +193,13 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
     int resident = 0;
     rc = get_queue_slot(&A.counters, &resident);
     if (rc) return rc;
-    BH_HIP(bh::launch_swd(A, resident, (hipStream_t)stream));
+    // Few searches: spend a whole wave on each (swd_team.h, ~10x lower latency); many: one lane
+    // each (swd_lane, ~5x more searches per second).  bh_swd_set_kernel overrides.
+    bool team = (long)B * ntargets <= (long)team_threshold();
+    if (g_swd_mode == BH_SWD_LANE) team = false;
+    if (g_swd_mode == BH_SWD_TEAM) team = true;
+    if (team) BH_HIP(bh::launch_swd_team(A, (hipStream_t)stream));
+    else BH_HIP(bh::launch_swd(A, resident, (hipStream_t)stream));
     return BH_OK;
 }
 

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "rf_core.h"
 #include "swd_core.h"
+#include "swd_team.h"
 
 namespace bh {
 
@@ -76,6 +77,83 @@ __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     LdsLay lay{lds + threadIdx.x, A.Lmax};
     QueueSrc src{A, tg, A.counters + t, t, 0};
     swd_lane(lay, src, tg, A.periods + tg.per_off, A.B, nullptr);
+}
+
+// ---------------------------------------------------------------------------------- SWD, team form
+// One wave per (model, target): swd_team.h.  The model's fp32 layer stack is shared by the wave
+// ([array][layer] in LDS); every lane runs the (wave-uniform) driver/control code on its own copy of
+// the search state, so the only communication is the per-round matrix/trial/value exchange in LDS.
+struct TeamLay {
+    float *base;
+    int L;
+    __device__ __forceinline__ float d(int i) const { return base[i]; }
+    __device__ __forceinline__ float a(int i) const { return base[L + i]; }
+    __device__ __forceinline__ float b(int i) const { return base[2 * L + i]; }
+    __device__ __forceinline__ float rho(int i) const { return base[3 * L + i]; }
+    __device__ __forceinline__ void set_d(int i, float v) { base[i] = v; }
+    __device__ __forceinline__ void set_a(int i, float v) { base[L + i] = v; }
+    __device__ __forceinline__ void set_b(int i, float v) { base[2 * L + i] = v; }
+    __device__ __forceinline__ void set_rho(int i, float v) { base[3 * L + i] = v; }
+};
+
+struct TeamSrc {
+    const SwdArgs &A;
+    const SwdTargetDev &tg;
+    int t, lane, taken;
+    long b;
+    __device__ __forceinline__ int next(TeamLay &lay, double *&out, double *&cws, double *&cbws)
+    {
+        if (taken) return 0;
+        taken = 1;
+        const int L = A.Lmax;
+        int nl = A.nlay[b];
+        nl = nl < 1 ? 1 : (nl > L ? L : nl);
+        const long g = b * A.mstride;
+        for (int l = lane; l < nl; l += SWD_T) {
+            lay.set_d(l, (float)A.h[g + l]);
+            lay.set_a(l, (float)A.vp[g + l]);
+            lay.set_b(l, (float)A.vs[g + l]);
+            lay.set_rho(l, (float)A.rho[g + l]);
+        }
+        __syncthreads();
+        out = A.out + b * A.out_stride + tg.out_off;
+        if (tg.mode > 1) {
+            cws = A.ws + ((long)t * 2 * BH_NP) * A.B + b;
+            cbws = cws + (long)BH_NP * A.B;
+        }
+        return nl;
+    }
+    __device__ __forceinline__ void done(int err)
+    {
+        if (lane == 0) A.err[b * A.ntargets + t] = err;
+    }
+};
+
+__global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A)
+{
+    extern __shared__ double tlds[];
+    const int lane = threadIdx.x;
+    const int t = blockIdx.y;
+    const SwdTargetDev tg = A.tg[t];
+    const int nm = A.Lmax > SWD_T ? A.Lmax : SWD_T;
+    double *mats = tlds, *trials = tlds + (long)nm * SWD_NCA, *dels = trials + SWD_TEAM_NT;
+    TeamLay lay{(float *)(dels + SWD_TEAM_NT), A.Lmax};
+    TeamSrc src{A, tg, t, lane, 0, (long)blockIdx.x};
+    const double *per = A.periods + tg.per_off;
+    SwdState S;
+    swd_state_init(S);
+    for (;;) {
+        swd_driver(S, lay, src, tg, per, A.B);
+        if (S.st == SWD_ST_DONE) break;
+        const int nt = swd_team_plan(S, SWD_T, trials);
+        __syncthreads();
+        swd_team_assemble(lay, lane, SWD_T, tg.iwave, S, nt, trials, mats);
+        __syncthreads();
+        swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
+        __syncthreads();
+        swd_team_consume(S, nt, trials, dels);
+        __syncthreads();
+    }
 }
 
 // -------------------------------------------------------------------------------------------- RF
@@ -152,6 +230,14 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
 }
 
 // ---------------------------------------------------------------------------------------- launch
+hipError_t launch_swd_team(const SwdArgs &A, hipStream_t stream)
+{
+    size_t lds = (size_t)swd_team_lds_doubles(A.Lmax, SWD_T) * sizeof(double) +
+                 (size_t)4 * A.Lmax * sizeof(float);
+    hipLaunchKernelGGL(swd_team_kernel, dim3(A.B, A.ntargets), dim3(SWD_T), lds, stream, A);
+    return hipGetLastError();
+}
+
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
 {
     size_t lds = (size_t)4 * A.Lmax * SWD_T * sizeof(float);

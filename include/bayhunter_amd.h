@@ -85,6 +85,14 @@ int  bh_set_device(int device);
  * err[b*ntargets + t]: the reference's err flag for that (model, target).
  * workspace: only needed when some target has mode > 1 (bh_swd_workspace_bytes). */
 size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets);
+/* Two kernels compute the same values: BH_SWD_LANE gives every lane its own search (throughput:
+ * ~6.5e6 searches/s, ~14 ms latency), BH_SWD_TEAM spends a wave per search (speculative bracketing
+ * + layer-parallel matrix assembly: ~10x lower latency, ~5x fewer searches/s).  BH_SWD_AUTO
+ * (default) picks by the number of searches in the call.  Process-wide setting. */
+#define BH_SWD_AUTO 0
+#define BH_SWD_LANE 1
+#define BH_SWD_TEAM 2
+int bh_swd_set_kernel(int mode);
 int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                  const double *vp, const double *vs, const double *rho, int ntargets,
                  const bh_swd_target *targets,

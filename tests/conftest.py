@@ -36,7 +36,7 @@ def _build_hostsim(name, extra):
     so = os.path.join(d, name)
     srcs = [os.path.join(d, 'hostsim.cpp')] + [
         os.path.join(ROOT, 'bayhunter_amd', 'csrc', f)
-        for f in ('bh_common.h', 'bh_math.h', 'swd_core.h', 'rf_core.h', 'rf_host.h')]
+        for f in ('bh_common.h', 'bh_math.h', 'swd_core.h', 'swd_team.h', 'rf_core.h', 'rf_host.h')]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.run(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off'] + extra +
                        ['-o', so, srcs[0]], check=True)
@@ -48,6 +48,10 @@ def _wrap_hostsim(hs):
     hs.hs_surfdisp96.restype = C.c_int
     hs.hs_surfdisp96.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, dp, dp, C.POINTER(C.c_long)]
+    hs.hs_surfdisp96_team.restype = C.c_int
+    hs.hs_surfdisp96_team.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, dp, dp, C.c_int, C.POINTER(C.c_long),
+                                      C.POINTER(C.c_long), C.POINTER(C.c_long)]
     hs.hs_rf.restype = C.c_int
     hs.hs_rf.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int,
                          C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp]
@@ -65,6 +69,18 @@ def _wrap_hostsim(hs):
             e = hs.hs_surfdisp96(*[x.ctypes.data_as(fp) for x in f], len(h), fl, iw, mode, ig,
                                  len(t), t.ctypes.data_as(dp), cg.ctypes.data_as(dp), C.byref(nc))
             return cg, e, nc.value
+
+        @staticmethod
+        def swd_team(h, vp, vs, rho, per, iw, ig, mode=1, fl=0, nlanes=64):
+            f = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32))
+                 for x in (h, vp, vs, rho)]
+            t = np.ascontiguousarray(per, dtype=np.float64)
+            cg = np.zeros(len(t))
+            nc, ns, nr = C.c_long(0), C.c_long(0), C.c_long(0)
+            e = hs.hs_surfdisp96_team(*[x.ctypes.data_as(fp) for x in f], len(h), fl, iw, mode, ig,
+                                      len(t), t.ctypes.data_as(dp), cg.ctypes.data_as(dp), nlanes,
+                                      C.byref(nc), C.byref(ns), C.byref(nr))
+            return cg, e, nc.value, ns.value, nr.value
 
         @staticmethod
         def rf(h, vp, vs, rho, p=6.4, gauss=1.0, nsamp=512, fsamp=5.0, tshift=5.0, nsv=None,

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include "../../bayhunter_amd/csrc/swd_core.h"
+#include "../../bayhunter_amd/csrc/swd_team.h"
 #include "../../bayhunter_amd/csrc/rf_core.h"
 #include "../../bayhunter_amd/csrc/rf_host.h"
 
@@ -53,6 +54,44 @@ extern "C" int hs_surfdisp96(const float *thkm, const float *vpm, const float *v
     std::vector<double> cws(kmax > 0 ? kmax : 1), cbws(kmax > 0 ? kmax : 1);
     OneTask src{HostLay{d.data(), a.data(), b.data(), r.data()}, nlayer, 0, -1, cg, cws.data(), cbws.data()};
     bh::swd_lane(lay, src, tg, t, 1, ncalls);
+    return src.err;
+}
+
+// CPU replay of the team kernel (swd_team.h): `nlanes` virtual lanes per search, phases separated
+// like the __syncthreads() of swd_team_kernel.  *ncalls counts consumed (= reference) evaluations,
+// *nspec all evaluations incl. discarded speculation, *nrounds the rounds.
+extern "C" int hs_surfdisp96_team(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                                  int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                                  const double *t, double *cg, int nlanes, long *ncalls, long *nspec,
+                                  long *nrounds)
+{
+    std::vector<float> d(thkm, thkm + nlayer), a(vpm, vpm + nlayer), b(vsm, vsm + nlayer),
+        r(rhom, rhom + nlayer);
+    HostLay lay{nullptr, nullptr, nullptr, nullptr};
+    bh::SwdTargetDev tg{iwave, igr, mode, iflsph, kmax, 0, 0, 0};
+    std::vector<double> cws(kmax > 0 ? kmax : 1), cbws(kmax > 0 ? kmax : 1);
+    OneTask src{HostLay{d.data(), a.data(), b.data(), r.data()}, nlayer, 0, -1, cg, cws.data(), cbws.data()};
+    std::vector<double> lds(bh::swd_team_lds_doubles(nlayer, nlanes));
+    double *mats = lds.data(), *trials = mats + lds.size() - 2 * bh::SWD_TEAM_NT,
+           *dels = trials + bh::SWD_TEAM_NT;
+    bh::SwdState S;
+    bh::swd_state_init(S);
+    long nc = 0, ns = 0, nr = 0;
+    for (;;) {
+        bh::swd_driver(S, lay, src, tg, t, 1);
+        if (S.st == bh::SWD_ST_DONE) break;
+        int nt = bh::swd_team_plan(S, nlanes, trials);
+        for (int lane = 0; lane < nlanes; lane++)
+            bh::swd_team_assemble(lay, lane, nlanes, iwave, S, nt, trials, mats);
+        for (int lane = 0; lane < nlanes; lane++)
+            bh::swd_team_chain(lay, lane, iwave, S, nt, trials, mats, dels);
+        nc += bh::swd_team_consume(S, nt, trials, dels);
+        ns += nt;
+        nr++;
+    }
+    if (ncalls) *ncalls = nc;
+    if (nspec) *nspec = ns;
+    if (nrounds) *nrounds = nr;
     return src.err;
 }
 

@@ -247,3 +247,51 @@ def test_full_size_properties(lib, oracle):
         want, werr, _ = oracle.swd_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl], per, iw, ig)
         _check_swd(name, o[sl, eng.slices[t]], want, e[sl, t], werr, monotone=True)
     assert np.abs(o[sl, eng.slices[4]] - oracle.rf_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl])).max() <= TOL_RF
+
+
+@pytest.fixture
+def team_mode(lib):
+    from bayhunter_amd import _lib
+    _lib.set_swd_kernel('team')
+    yield
+    _lib.set_swd_kernel('auto')
+
+
+@pytest.mark.parametrize('tag', ['L2_sorted', 'L10_sorted', 'L10_lvz', 'L31_lvz', 'ragged'])
+def test_team_kernel_golden_sets(lib, golden, team_mode, tag):
+    """The latency kernel (one wave per search) against the golden vectors, same tolerances."""
+    g = golden['swd_rf_random']
+    H, VP, VS, RHO = g[tag + '_model']
+    nl = g['ragged_nlay'] if tag == 'ragged' else _nlay(g[tag + '_model'])
+    eng = _engine([r[0] for r in REFS], g['periods'])
+    out, err = eng.run(H, VP, VS, RHO, nl)
+    out, err = out.cpu().numpy(), err.cpu().numpy()
+    for t, (name, _, _) in enumerate(REFS):
+        _check_swd(name, out[:, eng.slices[t]], g[tag + '_' + name], err[:, t], g[tag + '_' + name + '_err'],
+                   monotone=tag.endswith('sorted') or tag == 'ragged')
+
+
+def test_team_and_lane_kernels_agree_bitwise(lib, oracle):
+    """Both kernels run the same arithmetic per search -> identical bits, incl. modes, flsph, the
+    failure path, 1-layer and 100-layer models."""
+    from bayhunter_amd import _lib
+    per = np.linspace(1, 41, 21)
+    cases = [(draw_models(257, (1, 12), seed=11, sorted_vs=False), dict()),
+             (draw_models(64, 10, seed=12), dict(mode=2)),
+             (draw_models(64, 7, seed=13), dict(mode=3, flsph=1)),
+             (draw_models(6, 100, seed=14, zmax=300.0, thickmin=0.05), dict())]
+    for (H, VP, VS, RHO, nl), kw in cases:
+        res = {}
+        for mode in ('lane', 'team'):
+            _lib.set_swd_kernel(mode)
+            try:
+                eng = _engine([r[0] for r in REFS], per, **kw)
+                out, err = eng.run(H, VP, VS, RHO, nl)
+                res[mode] = (out.cpu().numpy(), err.cpu().numpy())
+            finally:
+                _lib.set_swd_kernel('auto')
+        assert np.array_equal(res['lane'][1], res['team'][1])
+        assert np.array_equal(res['lane'][0], res['team'][0])
+        if not kw:
+            want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, 2, 0)
+            assert np.array_equal(res['team'][1][:, 0], werr)

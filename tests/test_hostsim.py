@@ -24,6 +24,32 @@ def test_swd_state_machine_bitexact(oracle, hostsim, L, srt):
                 assert np.array_equal(a, r)
 
 
+@pytest.mark.parametrize('L,srt', [(1, True), (2, True), (5, True), (10, True), (10, False), (31, False), (80, True)])
+def test_swd_team_replay_bitexact(oracle, hostsim, L, srt):
+    """swd_team.h (speculative bracketing + layer-parallel assembly): same values, err flags and
+    number of CONSUMED period-equation evaluations as the reference; far fewer rounds."""
+    kw = dict(zmax=300.0, thickmin=0.05) if L > 40 else {}
+    H, VP, VS, RHO, nl = draw_models(6, L, seed=700 + L + int(srt), sorted_vs=srt, **kw)
+    per = np.linspace(1, 41, 21)
+    tot_calls = tot_rounds = 0
+    for name, iw, ig in REFS:
+        for mode, fl in ((1, 0), (2, 0), (3, 1)):
+            for b in range(6):
+                n = nl[b]
+                a, e1, n1 = oracle.swd(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], per, iw, ig,
+                                       mode, fl, count=True)
+                for nlanes in (64, 7):
+                    r, e2, n2, nspec, nrounds = hostsim.swd_team(H[b, :n], VP[b, :n], VS[b, :n],
+                                                                  RHO[b, :n], per, iw, ig, mode, fl, nlanes)
+                    assert e1 == e2 and n1 == n2 and nspec >= n2
+                    assert np.array_equal(a, r)
+                    if nlanes == 64:
+                        tot_calls += n2
+                        tot_rounds += nrounds
+    if L <= 10:
+        assert tot_rounds < 0.62 * tot_calls      # speculation pays when >= 6 trials fit a round
+
+
 def test_swd_nan_model_terminates(hostsim):
     """A NaN model must not spin forever (the reference would); it ends as 'no root'."""
     h = np.array([5., 10., 0.])

@@ -1,0 +1,30 @@
+"""GPU-box diagnostic: lane vs team SWD kernel over the number of searches (crossover)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bayhunter_amd import _lib
+from bayhunter_amd.engine import ForwardEngine, SwdSpec
+from bayhunter_amd.synthetic import draw_models
+
+def run(B, L, refs, P, mode, reps=3):
+    H, VP, VS, RHO, nl = draw_models(B, L, seed=1)
+    eng = ForwardEngine(swd=[SwdSpec(r, np.linspace(1, 41, P)) for r in refs])
+    d = eng.upload(H, VP, VS, RHO, nl)
+    out, err = eng.alloc_out(B)
+    _lib.set_swd_kernel(mode)
+    eng.run(*d, out=out, err=err); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.run(*d, out=out, err=err)
+    torch.cuda.synchronize()
+    _lib.set_swd_kernel('auto')
+    return (time.perf_counter() - t0) / reps * 1e3
+
+for L, refs, P in ((10, ['rdispph'], 21), (5, ['rdispph'], 20), (15, ['rdispph'], 21),
+                   (10, ['rdispph', 'rdispgr', 'ldispph', 'ldispgr'], 40)):
+    for B in (64, 256, 1024, 4096, 8192, 16384, 32768, 65536):
+        if len(refs) == 4 and B > 16384: continue
+        tl, tt = run(B, L, refs, P, 'lane'), run(B, L, refs, P, 'team')
+        print('L=%2d targets=%d P=%d B=%6d  lane %8.2f ms  team %8.2f ms  -> %s' % (L, len(refs), P, B, tl, tt, 'team' if tt < tl else 'lane'))
+        sys.stdout.flush()
