@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -96,6 +97,8 @@ int get_queue_slot(unsigned int **slot, int *resident_waves)
     }
     *slot = d.queue + (size_t)(d.next++ % kQueueSlots) * bh::BH_NT;
     *resident_waves = d.cus * 8;   // 2 waves/SIMD x 4 SIMDs (VGPR-limited, kernels.hip)
+    static const char *e = std::getenv("BH_SWD_RESIDENT_WAVES");   // test hook: forces the queue path
+    if (e && std::atoi(e) > 0) *resident_waves = std::atoi(e);
     return BH_OK;
 }
 
@@ -190,6 +193,8 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
     A.B = B; A.Lmax = Lmax; A.ntargets = ntargets; A.out_stride = out_stride; A.mstride = model_stride;
     A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.periods = periods;
     A.out = out; A.err = err; A.ws = (double *)workspace;
+    A.vec2 = (Lmax % 2 == 0 && model_stride % 2 == 0 &&
+              (((uintptr_t)h | (uintptr_t)vp | (uintptr_t)vs | (uintptr_t)rho) & 15) == 0) ? 1 : 0;
     int resident = 0;
     rc = get_queue_slot(&A.counters, &resident);
     if (rc) return rc;

@@ -16,6 +16,7 @@ constexpr int BH_NT = 16;   // BH_MAX_TARGETS
 struct SwdArgs {
     int B, Lmax, ntargets, out_stride;
     int mstride;             // elements between consecutive models in h/vp/vs/rho
+    int vec2;                // rows are 16-byte aligned and Lmax is even: fetch two layers per load
     const int *nlay;
     const double *h, *vp, *vs, *rho;
     const double *periods;

@@ -52,11 +52,24 @@ struct QueueSrc {
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         const long g = (long)b * A.mstride;
-        for (int l = 0; l < nl; l++) {
-            lay.set_d(l, (float)A.h[g + l]);
-            lay.set_a(l, (float)A.vp[g + l]);
-            lay.set_b(l, (float)A.vs[g + l]);
-            lay.set_rho(l, (float)A.rho[g + l]);
+        if (A.vec2) {   // rows 16-byte aligned: two layers per load (half the memory requests)
+            for (int l = 0; l < nl; l += 2) {
+                const double2 h2 = *(const double2 *)(A.h + g + l), a2 = *(const double2 *)(A.vp + g + l),
+                              b2 = *(const double2 *)(A.vs + g + l), r2 = *(const double2 *)(A.rho + g + l);
+                lay.set_d(l, (float)h2.x); lay.set_a(l, (float)a2.x);
+                lay.set_b(l, (float)b2.x); lay.set_rho(l, (float)r2.x);
+                if (l + 1 < nl) {
+                    lay.set_d(l + 1, (float)h2.y); lay.set_a(l + 1, (float)a2.y);
+                    lay.set_b(l + 1, (float)b2.y); lay.set_rho(l + 1, (float)r2.y);
+                }
+            }
+        } else {
+            for (int l = 0; l < nl; l++) {
+                lay.set_d(l, (float)A.h[g + l]);
+                lay.set_a(l, (float)A.vp[g + l]);
+                lay.set_b(l, (float)A.vs[g + l]);
+                lay.set_rho(l, (float)A.rho[g + l]);
+            }
         }
         out = A.out + (long)b * A.out_stride + tg.out_off;
         if (tg.mode > 1) {

@@ -295,3 +295,39 @@ def test_team_and_lane_kernels_agree_bitwise(lib, oracle):
         if not kw:
             want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, 2, 0)
             assert np.array_equal(res['team'][1][:, 0], werr)
+
+
+def test_work_queue_path(lib, oracle):
+    """The persistent-lane work queue only engages above ~4e5 searches per call; force it with a
+    tiny resident-wave budget (test hook BH_SWD_RESIDENT_WAVES) in a child process and compare with
+    the oracle: every lane then runs many searches back to back, on ragged models."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from bayhunter_amd import _lib
+from bayhunter_amd.engine import ForwardEngine, SwdSpec
+from bayhunter_amd.synthetic import draw_models
+H, VP, VS, RHO, nl = draw_models(3000, (2, 9), seed=21, sorted_vs=False)
+per = np.linspace(1, 41, 21)
+_lib.set_swd_kernel('lane')
+eng = ForwardEngine(swd=[SwdSpec('rdispph', per), SwdSpec('ldispgr', per)])
+out, err = eng.run(H, VP, VS, RHO, nl)
+np.savez(sys.argv[1], out=out.cpu().numpy(), err=err.cpu().numpy())
+""" % ROOT
+    path = os.path.join(ROOT, 'gpurun_out', 'queue_test.npz')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    env = dict(os.environ, BH_SWD_RESIDENT_WAVES='6')      # 3 waves per target -> ~16 searches per lane
+    subprocess.run([sys.executable, '-c', code, path], check=True, env=env)
+    got = np.load(path)
+    H, VP, VS, RHO, nl = draw_models(3000, (2, 9), seed=21, sorted_vs=False)
+    per = np.linspace(1, 41, 21)
+    for t, (iw, ig) in enumerate(((2, 0), (1, 1))):
+        want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, nthreads=8)
+        assert np.array_equal(got['err'][:, t], werr)
+        ok = werr == 0
+        d = np.abs(got['out'][ok][:, 21 * t:21 * (t + 1)] - want[ok])
+        assert d.max() <= (TOL_GROUP if ig else TOL_PHASE)
+        assert (d == 0).mean() >= 0.97
