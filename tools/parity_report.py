@@ -14,7 +14,10 @@ from oracle import pyoracle as po  # noqa: E402
 REFS = [('rdispph', 2, 0), ('rdispgr', 2, 1), ('ldispph', 1, 0), ('ldispgr', 1, 1)]
 
 
-def main(B=2048):
+def main(B=2048, kernel='auto'):
+    from bayhunter_amd import _lib
+    _lib.set_swd_kernel(kernel)
+    print('# swd kernel mode: %s, %d models per set' % (kernel, B))
     per = np.linspace(1, 41, 21)
     eng = ForwardEngine(swd=[SwdSpec(r[0], per) for r in REFS], rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
     threads = len(os.sched_getaffinity(0))
@@ -41,4 +44,4 @@ def main(B=2048):
 
 
 if __name__ == '__main__':
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 2048)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 2048, sys.argv[2] if len(sys.argv) > 2 else 'auto')
