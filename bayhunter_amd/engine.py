@@ -26,6 +26,17 @@ def rf_obsparams(obsx, ref='prf'):
     return fsamp, float(-obsx[0]), nsamp
 
 
+class DeviceModels(object):
+    """A batch of layered models resident in HBM: `packed` is [B, 4, Lmax] fp64 (h, vp, vs, rho
+    rows of each model contiguous, zero padded), `nlay` int32 [B].  H/VP/VS/RHO are views."""
+
+    def __init__(self, packed, nlay):
+        assert packed.dim() == 3 and packed.shape[1] == 4 and packed.is_contiguous()
+        self.packed, self.nlay = packed, nlay
+        self.B, self.Lmax = packed.shape[0], packed.shape[2]
+        self.H, self.VP, self.VS, self.RHO = (packed[:, i, :] for i in range(4))
+
+
 class SwdSpec(object):
     def __init__(self, ref, periods, mode=1, flsph=0):
         if ref not in SWD_REFS:
@@ -106,29 +117,28 @@ class ForwardEngine(object):
         return torch.from_numpy(np.ascontiguousarray(x)).to(device=self.device, dtype=dtype)
 
     def upload(self, H, VP, VS, RHO, nlay):
-        """[B, Lmax] arrays (+ int nlay[B]) -> device tensors in the packed [B, 4, Lmax] layout:
-        one contiguous 32*Lmax-byte block per model, which is what a lane fetches from the work
-        queue.  Returns views (H, VP, VS, RHO, nlay); views of an already packed tensor pass through."""
+        """[B, Lmax] arrays (+ int nlay[B]) -> DeviceModels: one packed [B, 4, Lmax] device tensor,
+        i.e. one contiguous 32*Lmax-byte block per model, which is what a lane fetches from the
+        work queue."""
         f64 = torch.float64
-        if isinstance(H, torch.Tensor) and getattr(H, '_bh_packed', None) is not None:
-            return H, VP, VS, RHO, self._as_dev(nlay, torch.int32)
         parts = [self._as_dev(x, f64) for x in (H, VP, VS, RHO)]
-        packed = torch.stack(parts, dim=1).contiguous()
-        views = [packed[:, i, :] for i in range(4)]
-        for v in views:
-            v._bh_packed = packed
-        return views[0], views[1], views[2], views[3], self._as_dev(nlay, torch.int32)
+        return DeviceModels(torch.stack(parts, dim=1).contiguous(), self._as_dev(nlay, torch.int32))
 
     def alloc_out(self, B):
         out = torch.empty((B, self.row), dtype=torch.float64, device=self.device)
         err = torch.empty((B, max(1, len(self.swd))), dtype=torch.int32, device=self.device)
         return out, err
 
-    def run(self, H, VP, VS, RHO, nlay, out=None, err=None, stream=None):
-        """Launch all targets for the batch (asynchronous).  Returns (out[B,row], err[B,nswd])."""
-        H, VP, VS, RHO, nlay = self.upload(H, VP, VS, RHO, nlay)
-        B, Lmax = H.shape
-        mstride = H.stride(0)
+    def run(self, H, VP=None, VS=None, RHO=None, nlay=None, out=None, err=None, stream=None):
+        """Launch all targets for the batch (asynchronous).  Either `run(models)` with resident
+        DeviceModels (from `upload` / models.layers_from_voronoi) or `run(H, VP, VS, RHO, nlay)`
+        with host or device arrays, which are packed first.  Returns (out[B,row], err[B,nswd])."""
+        models = H if isinstance(H, DeviceModels) else self.upload(H, VP, VS, RHO, nlay)
+        if models.packed.device != self.device:
+            raise ValueError("models live on %s, engine on %s" % (models.packed.device, self.device))
+        H, VP, VS, RHO, nlay = models.H, models.VP, models.VS, models.RHO, models.nlay
+        B, Lmax = models.B, models.Lmax
+        mstride = 4 * Lmax
         if out is None or err is None:
             out, err = self.alloc_out(B)
         st = torch.cuda.current_stream(self.device) if stream is None else stream

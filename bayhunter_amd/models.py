@@ -75,8 +75,8 @@ def make_priors(priors, thickmin=0., lowvelperc=None, highvelperc=None, mantle=N
 def layers_from_voronoi(VSN, ZV, nlay, vpvs, priors, thickmin=0., lowvelperc=None,
                         highvelperc=None, mantle=None, device=None, stream=None):
     """Batch on the GPU.  VSN, ZV: [B, Lmax] nuclei (rows sorted by depth, padding ignored),
-    nlay[B], vpvs[B].  Returns (H, VP, VS, RHO, valid): views of one packed [B, 4, Lmax] device
-    tensor (pass them straight to ForwardEngine.run / JointTarget.evaluate_batch) and int32 flags."""
+    nlay[B], vpvs[B].  Returns (models, valid): engine.DeviceModels (pass it straight to
+    ForwardEngine.run / JointTarget.evaluate_batch) and int32 prior-check flags."""
     import ctypes as C
     import torch
     lib = _lib.load()
@@ -98,7 +98,5 @@ def layers_from_voronoi(VSN, ZV, nlay, vpvs, priors, thickmin=0., lowvelperc=Non
         _lib.check(lib.bh_voronoi_to_layers(B, Lmax, nlay.data_ptr(), VSN.data_ptr(), ZV.data_ptr(),
                                             vpvs.data_ptr(), C.byref(pri), packed.data_ptr(),
                                             valid.data_ptr(), C.c_void_p(st.cuda_stream)))
-    views = [packed[:, i, :] for i in range(4)]
-    for v in views:
-        v._bh_packed = packed
-    return views[0], views[1], views[2], views[3], valid
+    from .engine import DeviceModels
+    return DeviceModels(packed, nlay), valid

@@ -273,17 +273,22 @@ class JointTarget(object):
             aux=torch.from_numpy(np.concatenate(aux) if aux else np.zeros(1)).to(dev))
         return self._batch
 
-    def evaluate_batch(self, H, VP, VS, nlay, noise, RHO=None, stream=None):
-        """Many models at once.  H, VP, VS (and RHO, default 0.77 + 0.32*VP like
-        src/Targets.py:319): [B, Lmax]; noise: [B, 2*ntargets] (corr, sigma per target).
-        Returns (logL[B], misfits[B, ntargets+1]) as device tensors (asynchronous)."""
+    def evaluate_batch(self, H, VP=None, VS=None, nlay=None, noise=None, RHO=None, stream=None):
+        """Many models at once: `evaluate_batch(models, noise=...)` with resident
+        engine.DeviceModels, or `evaluate_batch(H, VP, VS, nlay, noise)` with [B, Lmax] arrays (RHO
+        defaults to 0.77 + 0.32*VP like src/Targets.py:319).  noise: [B, 2*ntargets] (corr, sigma
+        per target).  Returns (logL[B], misfits[B, ntargets+1]) as device tensors (asynchronous)."""
         import torch
+        from .engine import DeviceModels
         bt = self._batch or self._build_batch()
         eng = bt['eng']
-        if RHO is None:
-            RHO = (torch.as_tensor(VP) * 0.32 + 0.77) * (torch.as_tensor(VS) > 0) \
-                if isinstance(VP, torch.Tensor) else np.where(np.asarray(VS) > 0, np.asarray(VP) * 0.32 + 0.77, 0.0)
-        out, err = eng.run(H, VP, VS, RHO, nlay, stream=stream)
+        if isinstance(H, DeviceModels):
+            out, err = eng.run(H, stream=stream)
+        else:
+            if RHO is None:
+                RHO = (torch.as_tensor(VP) * 0.32 + 0.77) * (torch.as_tensor(VS) > 0) \
+                    if isinstance(VP, torch.Tensor) else np.where(np.asarray(VS) > 0, np.asarray(VP) * 0.32 + 0.77, 0.0)
+            out, err = eng.run(H, VP, VS, RHO, nlay, stream=stream)
         B = out.shape[0]
         noise = eng._as_dev(noise, torch.float64)
         logL = torch.empty(B, dtype=torch.float64, device=eng.device)

@@ -200,11 +200,11 @@ def main():
         eng_only_rf._rfp[0].out_off = eng_swd._rfp[0].out_off
         eng_only_rf.row = eng_swd.row
     eng_only_swd.row = eng_swd.row
-    dH, dVP, dVS, dRHO, dnl = eng_swd.upload(H, VP, VS, RHO, nl)       # inputs resident in HBM
+    dmodels = eng_swd.upload(H, VP, VS, RHO, nl)                       # inputs resident in HBM
     out, err = eng_swd.alloc_out(B)
 
     def step():
-        eng_swd.run(dH, dVP, dVS, dRHO, dnl, out=out, err=err)
+        eng_swd.run(dmodels, out=out, err=err)
 
     for _ in range(args.warmup):
         step()
@@ -229,10 +229,10 @@ def main():
     eng_swd.overlap = False
     for i in range(nk):
         ev[i][0].record()
-        eng_only_swd.run(dH, dVP, dVS, dRHO, dnl, out=out, err=err)
+        eng_only_swd.run(dmodels, out=out, err=err)
         ev[i][1].record()
         if eng_only_rf:
-            eng_only_rf.run(dH, dVP, dVS, dRHO, dnl, out=out, err=err)
+            eng_only_rf.run(dmodels, out=out, err=err)
         ev[i][2].record()
     torch.cuda.synchronize()
     eng_swd.overlap = True

@@ -40,9 +40,8 @@ def test_gpu_voronoi_bitexact(lib, g, name):
     from bayhunter_amd.models import layers_from_voronoi
     priors, thickmin, lvz, hvz, mantle = SETUPS[name]
     VSN, ZV = np.nan_to_num(g['VSN'], nan=-7.0), np.nan_to_num(g['ZV'], nan=-7.0)   # padding is ignored
-    H, VP, VS, RHO, valid = layers_from_voronoi(VSN, ZV, g['nlay'], g['vpvs'], priors, thickmin, lvz,
-                                                hvz, mantle)
-    H, VP, VS, RHO, valid = (t.cpu().numpy() for t in (H, VP, VS, RHO, valid))
+    models, valid = layers_from_voronoi(VSN, ZV, g['nlay'], g['vpvs'], priors, thickmin, lvz, hvz, mantle)
+    H, VP, VS, RHO, valid = (t.cpu().numpy() for t in (models.H, models.VP, models.VS, models.RHO, valid))
     assert np.array_equal(valid, g[name + '_valid'])
     assert np.array_equal(H, g[name + '_H']) and np.array_equal(VP, g[name + '_VP'])
     live = np.arange(H.shape[1])[None, :] < g['nlay'][:, None]
@@ -60,13 +59,56 @@ def test_gpu_voronoi_feeds_engine(lib, oracle):
     VSN = np.sort(rs.uniform(2, 5, (B, L)), axis=1)
     ZV = np.sort(rs.uniform(0, 60, (B, L)), axis=1)
     nl = np.full(B, L, dtype=np.int32)
-    H, VP, VS, RHO, valid = layers_from_voronoi(VSN, ZV, nl, np.full(B, 1.73),
-                                                dict(layers=(1, 20), vs=(2, 5), z=(0, 60)), 0.1)
+    models, valid = layers_from_voronoi(VSN, ZV, nl, np.full(B, 1.73),
+                                        dict(layers=(1, 20), vs=(2, 5), z=(0, 60)), 0.1)
     per = np.linspace(1, 41, 21)
     eng = ForwardEngine(swd=[SwdSpec('rdispph', per)])
-    assert H.stride(0) == 4 * L
-    out, err = eng.run(H, VP, VS, RHO, nl)
-    want, werr, _ = oracle.swd_batch(H.cpu().numpy(), VP.cpu().numpy(), VS.cpu().numpy(),
-                                     RHO.cpu().numpy(), nl, per, 2, 0)
+    out, err = eng.run(models)
+    want, werr, _ = oracle.swd_batch(models.H.cpu().numpy(), models.VP.cpu().numpy(),
+                                     models.VS.cpu().numpy(), models.RHO.cpu().numpy(), nl, per, 2, 0)
     assert np.array_equal(err.cpu().numpy()[:, 0], werr)
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_full_device_pipeline_nuclei_to_loglikelihood(lib, oracle):
+    """Voronoi nuclei in, log-likelihood out, nothing else crosses the PCIe bus: voronoi_kernel ->
+    swd/rf kernels -> like_kernel, against the host path (NumPy Model + oracle synthetics +
+    JointTarget.evaluate)."""
+    from bayhunter_amd import targets as T
+    from bayhunter_amd.models import Model, layers_from_voronoi
+    rs = np.random.RandomState(9)
+    B, L = 96, 7
+    nl = rs.randint(2, L + 1, size=B).astype(np.int32)
+    VSN = np.sort(rs.uniform(2, 5, (B, L)), axis=1)
+    ZV = np.sort(rs.uniform(0, 60, (B, L)), axis=1)
+    vpvs = rs.uniform(1.6, 1.9, size=B)
+    per, trf = np.linspace(1, 41, 21), np.linspace(-5, 35, 201)
+    t1 = T.RayleighDispersionPhase(per, rs.normal(3.5, .2, 21))
+    t2 = T.PReceiverFunction(trf, rs.normal(0, .05, 201))
+    joint = T.JointTarget([t1, t2])
+    joint.set_target_covariance([True, False], [0.0, 0.6])
+    noise = np.stack([np.zeros(B), rs.uniform(.01, .05, B), rs.uniform(.3, .8, B), rs.uniform(.005, .02, B)], 1)
+    models, valid = layers_from_voronoi(VSN, ZV, nl, vpvs, dict(layers=(1, 20), vs=(2, 5), z=(0, 60)), 0.1)
+    logL, mis = joint.evaluate_batch(models, noise=noise)
+    logL, mis = logL.cpu().numpy(), mis.cpu().numpy()
+
+    class Fixed(object):
+        def __init__(self, x):
+            self.x, self.y = x, None
+
+        def run_model(self, h, vp, vs, rho, **kw):
+            return (self.x, self.y) if self.y is not None else (np.nan, np.nan)
+    p1, p2 = Fixed(per), Fixed(trf)
+    t1.update_plugin(p1)
+    t2.update_plugin(p2)
+    for b in range(0, B, 5):
+        n = nl[b]
+        vp, vs, h = Model.get_vp_vs_h(np.concatenate((VSN[b, :n], ZV[b, :n])), vpvs[b])
+        rho = vp * 0.32 + 0.77
+        y, err = oracle.swd(h, vp, vs, rho, per, 2, 0)
+        p1.y = y if err == 0 else None
+        p2.y = oracle.rf_model(h, vp, vs, rho, nout=201)
+        joint.evaluate(h=h, vp=vp, vs=vs, noise=noise[b])
+        assert np.isclose(logL[b], joint.proposallikelihood, rtol=1e-8)
+        assert np.allclose(mis[b], joint.proposalmisfits, rtol=1e-7)

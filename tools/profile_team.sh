@@ -11,7 +11,7 @@ from bayhunter_amd.synthetic import draw_models
 H,VP,VS,RHO,nl = draw_models(1024, 10, seed=1)
 eng = ForwardEngine(swd=[SwdSpec('rdispph', np.linspace(1,41,21))])
 d = eng.upload(H,VP,VS,RHO,nl)
-for _ in range(4): eng.run(*d)
+for _ in range(4): eng.run(d)
 torch.cuda.synchronize()
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /tmp/team_run.py > $OUT/trace.log 2>&1

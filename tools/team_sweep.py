@@ -13,10 +13,10 @@ def run(B, L, refs, P, mode, reps=3):
     d = eng.upload(H, VP, VS, RHO, nl)
     out, err = eng.alloc_out(B)
     _lib.set_swd_kernel(mode)
-    eng.run(*d, out=out, err=err); torch.cuda.synchronize()
+    eng.run(d, out=out, err=err); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        eng.run(*d, out=out, err=err)
+        eng.run(d, out=out, err=err)
     torch.cuda.synchronize()
     _lib.set_swd_kernel('auto')
     return (time.perf_counter() - t0) / reps * 1e3
