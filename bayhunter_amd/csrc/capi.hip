@@ -274,10 +274,18 @@ int bh_voronoi_to_layers(int B, int Lmax, const int *nlay, const double *vs_nucl
     return BH_OK;
 }
 
+size_t bh_likelihood_workspace_bytes(int B, int ntargets, const bh_like_target *targets)
+{
+    if (!targets || B <= 0) return 0;
+    for (int t = 0; t < ntargets; t++)
+        if (targets[t].cov == BH_COV_GAUSS) return (size_t)ntargets * (size_t)B * 2 * sizeof(double);
+    return 0;
+}
+
 int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, const double *out,
                         int out_stride, const int *err, int nflags, const double *yobs,
                         const double *noise, const double *aux, double *logL, double *misfits,
-                        void *stream)
+                        void *workspace, size_t workspace_bytes, void *stream)
 {
     if (B < 0 || ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("B/ntargets out of range");
     if (!targets || !out || !yobs || !noise || !logL || !misfits) return fail_arg("NULL pointer");
@@ -300,6 +308,8 @@ int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, cons
     A.B = B; A.ntargets = ntargets; A.out_stride = out_stride; A.nflags = nflags;
     A.out = out; A.err = err; A.yobs = yobs; A.noise = noise; A.aux = aux;
     A.logL = logL; A.misfits = misfits;
+    size_t need = bh_likelihood_workspace_bytes(B, ntargets, targets);
+    A.gq = (need > 0 && workspace && workspace_bytes >= need) ? (double *)workspace : nullptr;
     BH_HIP(bh::launch_like(A, nmax, (hipStream_t)stream));
     return BH_OK;
 }

@@ -65,6 +65,7 @@ struct LikeArgs {
     const int *err;
     const double *yobs, *noise, *aux;
     double *logL, *misfits;
+    double *gq;              // [ntargets][B][2] (q, sum d^2) of dense-Gaussian targets, or null
     LikeTargetDev tg[BH_NT];
 };
 

@@ -20,6 +20,91 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense Gaussian model on the FP64 matrix cores.  Y = D * R^-1 with D = residuals [models x n] and
+// the fixed R^-1 [n x n] is the one GEMM-shaped piece of the hot path (2*n^2 flops per model,
+// n = 201 for a receiver function); q_m = sum_i Y[m][i] * D[m][i].
+// One wave = 16 models.  v_mfma_f64_16x16x4_f64: A = D[16 models][4 k] (lane l: model l&15,
+// k = l>>4), B = R^-1[4 k][16 cols] (lane l: k = l>>4, col = l&15), C/D: col = l&15,
+// row = (l>>4) + 4*reg.  All ceil(n/16) column tiles are accumulated per k-step, so every
+// residual fragment is loaded once; R^-1 (323 KB at n = 201) streams from L2.
+// Writes q and sum(d^2) per model into `gq` [B][2]; like_kernel picks them up.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// NT column tiles per pass (NT*8 accumulator VGPRs); wider targets take several passes
+template <int NT>
+__global__ __launch_bounds__(64) void gauss_q_kernel(LikeArgs A, int t, double *gq)
+{
+    const LikeTargetDev tg = A.tg[t];
+    const long b0 = (long)blockIdx.x * 16;
+    const int lane = threadIdx.x;
+    const int n = tg.n;
+    const double *R = A.aux + tg.aux_off;
+    const int mrow = lane & 15, kq = lane >> 4;
+    const long bm = b0 + mrow;
+    const bool mvalid = bm < A.B;
+    const double *drow = A.out + (mvalid ? bm : b0) * (long)A.out_stride + tg.off;
+    const double *yobs = A.yobs + tg.off;
+    double q[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    const int ntiles = (n + 15) / 16;
+    for (int tb = 0; tb < ntiles; tb += NT) {
+        double4_t acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+        // software pipeline: the fragments of k-step s+1 are in flight while the NT MFMAs of step s
+        // issue (one wave per SIMD: nothing else hides the L2 latency of R^-1)
+        double an, bn[NT];
+        {
+            const int k = kq;
+            an = (mvalid && k < n) ? drow[k] - yobs[k] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int col = (tb + i) * 16 + mrow;
+                bn[i] = (k < n && col < n) ? R[(long)k * n + col] : 0.0;
+            }
+        }
+        for (int k0 = 0; k0 < n; k0 += 4) {
+            const double a = an;
+            double bv[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++) bv[i] = bn[i];
+            const int k = k0 + 4 + kq;
+            an = (mvalid && k < n) ? drow[k] - yobs[k] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int col = (tb + i) * 16 + mrow;
+                bn[i] = (k < n && col < n) ? R[(long)k * n + col] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[i], acc[i], 0, 0, 0);
+        }
+        // lane holds Y[model kq + 4r][col (tb+i)*16 + mrow]; dot with D over these columns
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long bmod = b0 + kq + 4 * r;
+            const bool ok = bmod < A.B;
+            const double *dr = A.out + (ok ? bmod : b0) * (long)A.out_stride + tg.off;
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int col = (tb + i) * 16 + mrow;
+                const double d = (ok && col < n) ? dr[col] - yobs[col] : 0.0;
+                q[r] += acc[i][r] * d;
+                s2[r] += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        for (int o = 8; o > 0; o >>= 1) {               // reduce over the 16 lanes sharing kq
+            q[r] += __shfl_xor(q[r], o, 64);
+            s2[r] += __shfl_xor(s2[r], o, 64);
+        }
+        const long bmod = b0 + kq + 4 * r;
+        if (mrow == 0 && bmod < A.B) { gq[bmod * 2] = q[r]; gq[bmod * 2 + 1] = s2[r]; }
+    }
+}
+
 __global__ __launch_bounds__(LIKE_T) void like_kernel(LikeArgs A)
 {
     extern __shared__ double sm[];          // [LIKE_M][nmax] residuals, then [LIKE_M][4] partials
@@ -52,7 +137,17 @@ __global__ __launch_bounds__(LIKE_T) void like_kernel(LikeArgs A)
         }
         __syncthreads();
 
-        if (tg.cov == 3) {
+        if (tg.cov == 3 && A.gq) {
+            // precomputed on the matrix cores (gauss_q_kernel)
+            if (tid < LIKE_M) {
+                for (int w = 0; w < NW; w++) { red[tid][w][0] = 0.0; red[tid][w][1] = 0.0; }
+                if (tid < Mb) {
+                    const double *g = A.gq + ((long)t * A.B + (b0 + tid)) * 2;
+                    red[tid][0][1] = g[0];
+                    red[tid][0][0] = g[1];
+                }
+            }
+        } else if (tg.cov == 3) {
             // q_m = d_m^T R^-1 d_m : thread i owns row i for all LIKE_M models
             const double *R = A.aux + tg.aux_off;
             double s2[LIKE_M], q[LIKE_M];
@@ -204,6 +299,19 @@ hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream)
 
 hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
 {
+    if (A.gq) {   // dense Gaussian targets first, on the FP64 MFMA
+        for (int t = 0; t < A.ntargets; t++)
+            if (A.tg[t].cov == 3)
+            {
+                const int nt = (A.tg[t].n + 15) / 16;
+                const dim3 g((A.B + 15) / 16), b(64);
+                double *gq = A.gq + (long)t * A.B * 2;
+                if (nt <= 4) hipLaunchKernelGGL(gauss_q_kernel<4>, g, b, 0, stream, A, t, gq);
+                else if (nt <= 8) hipLaunchKernelGGL(gauss_q_kernel<8>, g, b, 0, stream, A, t, gq);
+                else if (nt == 13) hipLaunchKernelGGL(gauss_q_kernel<13>, g, b, 0, stream, A, t, gq);
+                else hipLaunchKernelGGL(gauss_q_kernel<16>, g, b, 0, stream, A, t, gq);
+            }
+    }
     size_t lds = (size_t)LIKE_M * nmax * sizeof(double);
     static thread_local size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {

@@ -186,6 +186,7 @@ class JointTarget(object):
         self.targets = targets
         self.ntargets = len(targets)
         self._batch = None
+        self.use_mfma = True     # dense Gaussian covariance product on the FP64 matrix cores
 
     def get_misfits(self):
         misfits = [target.valuation.misfit for target in self.targets]
@@ -294,9 +295,14 @@ class JointTarget(object):
         logL = torch.empty(B, dtype=torch.float64, device=eng.device)
         misfits = torch.empty((B, self.ntargets + 1), dtype=torch.float64, device=eng.device)
         st = torch.cuda.current_stream(eng.device) if stream is None else stream
+        need = eng.lib.bh_likelihood_workspace_bytes(B, self.ntargets, bt['desc']) if self.use_mfma else 0
+        ws = bt.get('ws')
+        if need and (ws is None or ws.numel() * 8 < need):
+            ws = bt['ws'] = torch.empty((need + 7) // 8, dtype=torch.float64, device=eng.device)
         with torch.cuda.device(eng.device):
             _lib.check(eng.lib.bh_likelihood_batch(
                 B, self.ntargets, bt['desc'], out.data_ptr(), eng.row, err.data_ptr(), bt['nflags'],
                 bt['yobs'].data_ptr(), noise.data_ptr(), bt['aux'].data_ptr(), logL.data_ptr(),
-                misfits.data_ptr(), C.c_void_p(st.cuda_stream)))
+                misfits.data_ptr(), ws.data_ptr() if need else None, need,
+                C.c_void_p(st.cuda_stream)))
         return logL, misfits

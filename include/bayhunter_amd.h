@@ -151,10 +151,14 @@ typedef struct bh_like_target {
 } bh_like_target;
 /* yobs: observed data laid out like an output row [row_len]; noise: [B][2*ntargets] (corr, sigma)
  * pairs per target (src/Targets.py:338); err: [B][nflags] int32 flags (may be NULL with nflags 0). */
+/* workspace: bh_likelihood_workspace_bytes() bytes of device memory when a BH_COV_GAUSS target is
+ * present (its n x n product runs on the FP64 matrix cores and parks d^T R^-1 d there); with a NULL
+ * / too small workspace the product falls back to the vector units inside the same call. */
+size_t bh_likelihood_workspace_bytes(int B, int ntargets, const bh_like_target *targets);
 int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, const double *out,
                         int out_stride, const int *err, int nflags, const double *yobs,
                         const double *noise, const double *aux, double *logL, double *misfits,
-                        void *stream);
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- single-model drop-ins (host pointers, synchronous) --------------------------------- */
 /* Same argument list as the f2py wrapper of `subroutine surfdisp96`; model arrays are real*4 with
