@@ -170,6 +170,7 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
     if (model_stride < Lmax) return fail_arg("model_stride < Lmax");
     if (ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("ntargets out of range");
+    if (B == 0) return BH_OK;   // nothing to do; an empty device buffer may legitimately be NULL
     if (!nlay || !h || !vp || !vs || !rho || !targets || !periods || !out || !err)
         return fail_arg("NULL pointer");
     int rc = ensure_device();
@@ -218,6 +219,7 @@ static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, 
     if (!par) return fail_arg("par is NULL");
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
     if (model_stride < Lmax) return fail_arg("model_stride < Lmax");
+    if (B == 0) return BH_OK;
     if (!nlay || !h || !vp || !vs || !rho || !out) return fail_arg("NULL pointer");
     int n = par->nsamp;
     if (n < 8 || n > 4096 || (n & (n - 1))) return fail_arg("nsamp must be a power of two in 8..4096");
@@ -260,6 +262,7 @@ int bh_voronoi_to_layers(int B, int Lmax, const int *nlay, const double *vs_nucl
                          double *model, int *valid, void *stream)
 {
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
+    if (B == 0) return BH_OK;
     if (!nlay || !vs_nuclei || !z_nuclei || !vpvs || !pri || !model || !valid) return fail_arg("NULL pointer");
     int rc = ensure_device();
     if (rc) return rc;
@@ -288,6 +291,7 @@ int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, cons
                         void *workspace, size_t workspace_bytes, void *stream)
 {
     if (B < 0 || ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("B/ntargets out of range");
+    if (B == 0) return BH_OK;
     if (!targets || !out || !yobs || !noise || !logL || !misfits) return fail_arg("NULL pointer");
     if (nflags < 0 || (nflags > 0 && !err)) return fail_arg("err is NULL but nflags > 0");
     int rc = ensure_device();

@@ -331,3 +331,27 @@ np.savez(sys.argv[1], out=out.cpu().numpy(), err=err.cpu().numpy())
         d = np.abs(got['out'][ok][:, 21 * t:21 * (t + 1)] - want[ok])
         assert d.max() <= (TOL_GROUP if ig else TOL_PHASE)
         assert (d == 0).mean() >= 0.97
+
+
+def test_engine_corner_cases(lib, oracle):
+    """RF-only engine, empty batch, nsamp 4096 with 100 layers (one model per workgroup, 102 KB of
+    LDS in the SWD kernel), SV receiver function through the batched path."""
+    import torch
+    from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
+    H, VP, VS, RHO, nl = draw_models(5, 100, seed=31, zmax=300.0, thickmin=0.05)
+    x = np.arange(1500) / 20.0 - 5.0                               # 1500 samples @ 20 Hz -> nsamp 4096
+    eng = ForwardEngine(rf=[RfSpec('srf', x, gauss=2.0, p=5.0)])
+    assert int(eng.rf[0].nsamp) == 4096
+    out, err = eng.run(H, VP, VS, RHO, nl)
+    want = oracle.rf_batch(H, VP, VS, RHO, nl, p=5.0, gauss=2.0, nsamp=4096, fsamp=20.0, tshift=5.0,
+                           waveno=1, nout=1500)
+    assert np.abs(out.cpu().numpy() - want).max() <= TOL_RF * max(1.0, np.abs(want).max())
+    assert int(err.sum().item()) == 0
+    # empty batch
+    eng2 = ForwardEngine(swd=[SwdSpec('rdispph', np.linspace(1, 41, 21))], rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
+    out, err = eng2.run(np.zeros((0, 4)), np.zeros((0, 4)), np.zeros((0, 4)), np.zeros((0, 4)), np.zeros(0, dtype=np.int32))
+    torch.cuda.synchronize()
+    assert out.shape == (0, 222) and err.shape == (0, 1)
+    # model on the wrong device / bad shapes are host errors, not kernel faults
+    with pytest.raises(Exception):
+        eng2.run(np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)), np.ones(3, dtype=np.int32))

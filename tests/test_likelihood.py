@@ -142,3 +142,44 @@ def test_gpu_evaluate_batch_large_consistent_with_host(lib, g):
         joint.evaluate(h=H[b, :nl[b]], vp=VP[b, :nl[b]], vs=VS[b, :nl[b]], noise=noise[b])
         assert np.isclose(logL[b], joint.proposallikelihood, rtol=1e-11)
         assert np.allclose(mis[b], joint.proposalmisfits, rtol=1e-11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [5, 64, 130, 300, 1024])
+def test_gpu_gauss_quadratic_form_all_tile_shapes(lib, n):
+    """bh_likelihood_batch straight through the C ABI for dense-Gaussian targets of every MFMA tile
+    variant (4/8/13/16 column tiles, multi-pass above 256 points), with and without the matrix-core
+    workspace, no err-flag columns, batch not a multiple of 16; against NumPy with an ASYMMETRIC
+    'R^-1' (catches a transposed operand) ."""
+    import ctypes as C
+    import torch
+    from bayhunter_amd import _lib
+    rs = np.random.RandomState(n)
+    B = 37
+    out = rs.normal(size=(B, n + 3))
+    yobs = np.zeros(n + 3)
+    yobs[3:] = rs.normal(size=n)
+    Rinv = rs.normal(size=(n, n)) / n                      # deliberately not symmetric
+    noise = np.stack([np.full(B, 0.9), rs.uniform(0.5, 2.0, B)], axis=1)
+    d = out[:, 3:] - yobs[3:]
+    q = np.einsum('bi,ij,bj->b', d, Rinv, d)
+    want = -0.5 * (n * np.log(2 * np.pi) + 2 * n * np.log(noise[:, 1]) + 1.25) - q / noise[:, 1] ** 2 / 2
+    want_mis = np.sqrt((d ** 2).mean(axis=1))
+    dev = torch.device('cuda')
+    t_out, t_yobs, t_noise, t_aux = (torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                                     for a in (out, yobs, noise, Rinv.ravel()))
+    desc = (_lib.LikeTarget * 1)(_lib.LikeTarget(n, 3, _lib.COV_GAUSS, 0, 1.25))
+    need = lib.bh_likelihood_workspace_bytes(B, 1, desc)
+    assert need == B * 2 * 8
+    ws = torch.empty(need // 8, dtype=torch.float64, device=dev)
+    for use_ws in (True, False):
+        logL = torch.zeros(B, dtype=torch.float64, device=dev)
+        mis = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+        _lib.check(lib.bh_likelihood_batch(B, 1, desc, t_out.data_ptr(), n + 3, None, 0, t_yobs.data_ptr(),
+                                           t_noise.data_ptr(), t_aux.data_ptr(), logL.data_ptr(),
+                                           mis.data_ptr(), ws.data_ptr() if use_ws else None,
+                                           need if use_ws else 0, None))
+        torch.cuda.synchronize()
+        assert np.allclose(logL.cpu().numpy(), want, rtol=1e-11, atol=1e-9)
+        assert np.allclose(mis.cpu().numpy()[:, 0], want_mis, rtol=1e-12)
+        assert np.allclose(mis.cpu().numpy()[:, 1], want_mis, rtol=1e-12)
