@@ -73,12 +73,53 @@ BH_DEV cd operator/(cd x, cd y)
     return mk(((b * ratio) + a) / denom, (b - (a * ratio)) / denom);
 }
 BH_DEV cd rdiv(double x, cd y) { return mk(x, 0.0) / y; }
-// 1/z = conj(z)/|z|^2: one real division instead of Smith's three; for the well-scaled values of
-// the per-frequency recursion (|z| within 1e-3..1e3)
+// Fast reciprocal / square root for the tolerance-checked receiver-function recursion: hardware
+// seed (v_rcp_f64 / v_rsq_f64) + Newton steps, ~1 ulp, half the instructions of the IEEE sequences.
+// Arguments there are well scaled (1e-6..1e6) and non-zero.
+#if defined(BH_HOSTSIM)
+BH_DEV double frcp(double x) { return 1.0 / x; }
+BH_DEV double fsqrt(double x) { return sqrt(x); }
+#else
+BH_DEV double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+BH_DEV double fsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);          // ~ 1/sqrt(x)
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x > 0.0) ? g : ((x == 0.0) ? 0.0 : __builtin_nan(""));
+}
+#endif
+
+// 1/z = conj(z)/|z|^2: one real reciprocal instead of Smith's three divisions
 BH_DEV cd crecip(cd z)
 {
-    double r = 1.0 / (z.re * z.re + z.im * z.im);
+    double r = frcp(z.re * z.re + z.im * z.im);
     return mk(z.re * r, -(z.im * r));
+}
+
+// principal square root for generic complex arguments of the recursion (im != 0)
+BH_DEV cd csqrt_fast(cd z)
+{
+    double re = z.re, im = z.im;
+    double d = fsqrt(re * re + im * im), r, s;
+    if (re > 0) {
+        r = fsqrt(0.5 * (d + re));
+        s = 0.5 * (im * frcp(r));
+    } else {
+        s = fsqrt(0.5 * (d - re));
+        r = fabs(0.5 * (im * frcp(s)));
+    }
+    return mk(r, copysign(s, im));
 }
 
 // principal square root, glibc csqrt's formulation for finite non-zero arguments

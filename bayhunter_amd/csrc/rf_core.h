@@ -264,10 +264,10 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
         double d = par[i], vp = par[lo.L + i], vs = par[2 * lo.L + i], qp = par[4 * lo.L + i],
                qs = par[5 * lo.L + i];
         cd miwd = mk(0., -w * d);
-        cd vpc = mk(1. + lgw / (BH_PI * qp), 1. / (2. * qp)) * vp;   // Mueller (1985) eq. 132
-        cd vsc = mk(1. + lgw / (BH_PI * qs), 1. / (2. * qs)) * vs;
-        cd plc = csqrt_(crecip(vpc * vpc) - P.p2);
-        cd slc = csqrt_(crecip(vsc * vsc) - P.p2);
+        cd vpc = mk(1. + lgw * frcp(BH_PI * qp), frcp(2. * qp)) * vp;   // Mueller (1985) eq. 132
+        cd vsc = mk(1. + lgw * frcp(BH_PI * qs), frcp(2. * qs)) * vs;
+        cd plc = csqrt_fast(crecip(vpc * vpc) - P.p2);               // Q finite -> im != 0
+        cd slc = csqrt_fast(crecip(vsc * vsc) - P.p2);
         cd e11 = cexp_(miwd * plc), e22 = cexp_(miwd * slc);
         const double *ci = coef + 32 * i, *cn = coef + 32 * (i + 1);
         cm2 nt;
