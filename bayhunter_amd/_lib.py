@@ -97,6 +97,7 @@ _SIGS = {
                                 C.c_int, _vp, _vp, C.POINTER(C.c_int)]),
     "bh_synrf": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                            C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bh_selftest_division": (C.c_int, [C.c_long, C.c_uint, C.c_int, C.POINTER(C.c_long)]),
     "bh_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "bh_free": (C.c_int, [_vp]),
     "bh_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),

@@ -412,6 +412,21 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
     return BH_OK;
 }
 
+int bh_selftest_division(long n, unsigned seed, int max_exp, long *mismatches)
+{
+    if (!mismatches || n < 0 || max_exp < 0 || max_exp > 500) return fail_arg("bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    unsigned long long *d = nullptr, h = 0;
+    BH_HIP(hipMalloc((void **)&d, sizeof(h)));
+    BH_HIP(hipMemset(d, 0, sizeof(h)));
+    BH_HIP(bh::launch_division_selftest(n, seed, max_exp, d, nullptr));
+    BH_HIP(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
+    BH_HIP(hipFree(d));
+    *mismatches = (long)h;
+    return BH_OK;
+}
+
 // ---- plumbing ----------------------------------------------------------------------------------
 int bh_malloc(void **dptr, size_t bytes)
 {

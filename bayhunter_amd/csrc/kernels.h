@@ -50,6 +50,7 @@ struct VoronoiArgs {
     ModelPriorsDev pri;
 };
 hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream);
+hipError_t launch_division_selftest(long n, unsigned seed, int max_exp, unsigned long long *bad, hipStream_t stream);
 
 struct LikeTargetDev {
     int n, off, cov, aux_off;

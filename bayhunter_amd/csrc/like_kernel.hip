@@ -291,6 +291,43 @@ __global__ __launch_bounds__(256) void voronoi_kernel(VoronoiArgs A)
     A.valid[b] = ok ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Self-test of the shared-reciprocal division (bh_common.h) against the `/` operator.
+__device__ __forceinline__ unsigned long long xs64(unsigned long long &s)
+{
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    return s;
+}
+__device__ __forceinline__ double rnd_double(unsigned long long &s, int max_exp)
+{
+    unsigned long long m = xs64(s) & 0x000fffffffffffffULL;
+    int e = (int)(xs64(s) % (unsigned)(2 * max_exp + 1)) - max_exp;
+    unsigned long long sign = (xs64(s) & 1ULL) << 63;
+    unsigned long long bits = sign | ((unsigned long long)(e + 1023) << 52) | m;
+    return __longlong_as_double((long long)bits);
+}
+__global__ void division_selftest_kernel(long n, unsigned seed, int max_exp, unsigned long long *bad)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    unsigned long long s = 0x9E3779B97F4A7C15ULL ^ ((unsigned long long)seed << 32) ^ (unsigned long long)(i * 2654435761UL + 1);
+    unsigned long long nbad = 0;
+    for (; i < n; i += stride) {
+        const double a = rnd_double(s, max_exp), b = rnd_double(s, max_exp), c = rnd_double(s, max_exp);
+        const Recip R = recip_of(b);
+        const double q1 = qdiv(a, R), q2 = qdiv(c, R);
+        const double r1 = a / b, r2 = c / b;
+        if (__double_as_longlong(q1) != __double_as_longlong(r1)) nbad++;
+        if (__double_as_longlong(q2) != __double_as_longlong(r2)) nbad++;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+hipError_t launch_division_selftest(long n, unsigned seed, int max_exp, unsigned long long *bad, hipStream_t stream)
+{
+    hipLaunchKernelGGL(division_selftest_kernel, dim3(2048), dim3(256), 0, stream, n, seed, max_exp, bad);
+    return hipGetLastError();
+}
+
 hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream)
 {
     hipLaunchKernelGGL(voronoi_kernel, dim3((A.B + 255) / 256), dim3(256), 0, stream, A);

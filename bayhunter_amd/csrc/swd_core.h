@@ -33,7 +33,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
     double pex = 0.0, sex = 0.0;
     if (wvno < xka) {
         bh_sincos(p, &sinp, &cosp);
-        w = sinp / ra;
+        w = xdiv(sinp, ra);
         x = -ra * sinp;
     } else if (wvno == xka) {
         cosp = 1.0; w = dpth; x = 0.0;
@@ -43,12 +43,12 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
         if (p < 16) fac = bh_exp(-2.0 * p);
         cosp = (1.0 + fac) * 0.5;
         sinp = (1.0 - fac) * 0.5;
-        w = sinp / ra;
+        w = xdiv(sinp, ra);
         x = ra * sinp;
     }
     if (wvno < xkb) {
         bh_sincos(q, &sinq, &cosq);
-        y = sinq / rb;
+        y = xdiv(sinq, rb);
         z = -rb * sinq;
     } else if (wvno == xkb) {
         cosq = 1.0; y = dpth; z = 0.0;
@@ -58,7 +58,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
         if (q < 16) fac = bh_exp(-2.0 * q);
         cosq = (1.0 + fac) * 0.5;
         sinq = (1.0 - fac) * 0.5;
-        y = sinq / rb;
+        y = xdiv(sinq, rb);
         z = rb * sinq;
     }
     double exa = pex + sex;
@@ -85,10 +85,11 @@ BH_DEV void swd_dnka(Dunkin &a, double wvno2, double gam, double gammk, double r
     double gamm1 = gam - one, twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1,
            gm1sq = gamm1 * gamm1, rho2 = rho * rho, a0pq = v.a0 - v.cpcq;
     a.c11 = v.cpcq - two * gmgm1 * a0pq - gmgmk * v.xz - wvno2 * gm1sq * v.wy;
-    a.c12 = (wvno2 * v.cpy - v.cqx) / rho;
-    a.c13 = -(twgm1 * a0pq + gammk * v.xz + wvno2 * gamm1 * v.wy) / rho;
-    a.c14 = (v.cpz - wvno2 * v.cqw) / rho;
-    a.c15 = -(two * wvno2 * a0pq + v.xz + wvno2 * wvno2 * v.wy) / rho2;
+    const Recip by_rho = recip_of(rho);
+    a.c12 = qdiv(wvno2 * v.cpy - v.cqx, by_rho);
+    a.c13 = qdiv(-(twgm1 * a0pq + gammk * v.xz + wvno2 * gamm1 * v.wy), by_rho);
+    a.c14 = qdiv(v.cpz - wvno2 * v.cqw, by_rho);
+    a.c15 = xdiv(-(two * wvno2 * a0pq + v.xz + wvno2 * wvno2 * v.wy), rho2);
     a.c21 = (gmgmk * v.cpz - gm1sq * v.cqw) * rho;
     a.c22 = v.cpcq;
     a.c23 = gammk * v.cpz - gamm1 * v.cqw;
@@ -123,7 +124,9 @@ BH_DEV void swd_dunkin_apply(double e[5], const Dunkin &a)
     if (fabs(ee4) > t1) t1 = fabs(ee4);
     if (fabs(ee5) > t1) t1 = fabs(ee5);
     if (t1 < 1.e-40) t1 = 1.0;
-    e[0] = ee1 / t1; e[1] = ee2 / t1; e[2] = ee3 / t1; e[3] = ee4 / t1; e[4] = ee5 / t1;
+    const Recip by_t1 = recip_of(t1);
+    e[0] = qdiv(ee1, by_t1); e[1] = qdiv(ee2, by_t1); e[2] = qdiv(ee3, by_t1);
+    e[3] = qdiv(ee4, by_t1); e[4] = qdiv(ee5, by_t1);
 }
 
 // Dunkin matrix of layer i0 (0-based) at (wvno, omega): the loop body of surfdisp96.f:813-837.
@@ -133,9 +136,9 @@ BH_DEV void swd_ray_layer_matrix(const Lay &lay, int i0, double wvno, double wvn
                                  Dunkin &a)
 {
     double am = (double)lay.a(i0), bm = (double)lay.b(i0);
-    double xka = omega / am;
-    double xkb = omega / bm;
-    double t = bm / omega;
+    double xka = xdiv(omega, am);
+    double xkb = xdiv(omega, bm);
+    double t = xdiv(bm, omega);
     double gammk = 2.0 * t * t;
     double gam = gammk * wvno2;
     double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
@@ -217,13 +220,13 @@ BH_DEV void swd_love_layer(const Lay &lay, int i0, double wvno, double omega, Lo
     double rho1 = (double)lay.rho(i0);
     double dm = (double)lay.d(i0);
     o.xmu = rho1 * beta1 * beta1;
-    double xkb = omega / beta1;
+    double xkb = xdiv(omega, beta1);
     double wvnop = wvno + xkb, wvnom = fabs(wvno - xkb);
     double rb = sqrt(wvnop * wvnom);
     double q = dm * rb, sinq, fac;
     if (wvno < xkb) {
         bh_sincos(q, &sinq, &o.cosq);
-        o.y = sinq / rb;
+        o.y = xdiv(sinq, rb);
         o.z = -rb * sinq;
     } else if (wvno == xkb) {
         o.cosq = 1.0; o.y = dm; o.z = 0.0;
@@ -232,7 +235,7 @@ BH_DEV void swd_love_layer(const Lay &lay, int i0, double wvno, double omega, Lo
         if (q < 16) fac = bh_exp(-2.0 * q);
         o.cosq = (1.0 + fac) * 0.5;
         sinq = (1.0 - fac) * 0.5;
-        o.y = sinq / rb;
+        o.y = xdiv(sinq, rb);
         o.z = rb * sinq;
     }
 }
@@ -240,12 +243,13 @@ BH_DEV void swd_love_layer(const Lay &lay, int i0, double wvno, double omega, Lo
 BH_DEV void swd_love_apply(double &e1, double &e2, const LoveLayer &o)
 {
     double e10 = e1 * o.cosq + e2 * o.xmu * o.z;
-    double e20 = e1 * o.y / o.xmu + e2 * o.cosq;
+    double e20 = xdiv(e1 * o.y, o.xmu) + e2 * o.cosq;
     double xnor = fabs(e10), ynor = fabs(e20);
     if (ynor > xnor) xnor = ynor;
     if (xnor < 1.e-40) xnor = 1.0;
-    e1 = e10 / xnor;
-    e2 = e20 / xnor;
+    const Recip by_nor = recip_of(xnor);
+    e1 = qdiv(e10, by_nor);
+    e2 = qdiv(e20, by_nor);
 }
 // surfdisp96.f:723-730
 template <class Lay>

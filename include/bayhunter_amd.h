@@ -172,6 +172,12 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
              const double *rh, const double *qp, const double *qs,
              double *fz, double *fr, double *rf);
 
+/* ---- self-test --------------------------------------------------------------------------- */
+/* The surface-wave kernels divide with a shared-reciprocal form of the compiler's own IEEE sequence
+ * (bh_common.h, Recip/qdiv).  This runs n pseudo-random fp64 quotients a/b with exponents in
+ * [-max_exp, max_exp] on the device both ways and counts bitwise differences (expected: 0). */
+int bh_selftest_division(long n, unsigned seed, int max_exp, long *mismatches);
+
 /* ---- plumbing for hosts without their own device allocator ------------------------------ */
 int bh_malloc(void **dptr, size_t bytes);
 int bh_free(void *dptr);

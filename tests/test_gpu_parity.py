@@ -355,3 +355,15 @@ def test_engine_corner_cases(lib, oracle):
     # model on the wrong device / bad shapes are host errors, not kernel faults
     with pytest.raises(Exception):
         eng2.run(np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)), np.ones(3, dtype=np.int32))
+
+
+def test_division_selftest(lib):
+    """The shared-reciprocal division of the SWD kernels is bit-identical to the IEEE `/` operator:
+    2 x 2^26 random quotients at moderate exponents (the period equation's range) and 2 x 2^24 over
+    2^-300..2^300."""
+    import ctypes as C
+    from bayhunter_amd import _lib
+    for n, max_exp in ((1 << 26, 40), (1 << 24, 300)):
+        bad = C.c_long(-1)
+        _lib.check(lib.bh_selftest_division(n, 12345 + max_exp, max_exp, C.byref(bad)))
+        assert bad.value == 0, (max_exp, bad.value)
