@@ -65,6 +65,25 @@ BH_DEV double qdiv(double a, const Recip &R)
 #endif
 BH_DEV double xdiv(double a, double b) { return qdiv(a, recip_of(b)); }
 
+// IEEE square root for arguments that are zero or in the normal range (no denormals, no Inf): the
+// compiler's own sequence (v_rsq, one coupled Newton step, two residual corrections) without its
+// 2^256 range scaling.  Bit-identical to sqrt() there (bh_selftest_division).
+#if defined(BH_HOSTSIM)
+BH_DEV double xsqrt(double x) { return sqrt(x); }
+#else
+BH_DEV double xsqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return (x == 0.0) ? x : g;
+}
+#endif
+
 BH_DEV double dsign1(double x) { return copysign(1.0, x); }
 BH_DEV double dmin(double a, double b) { return a < b ? a : b; }
 BH_DEV double dmax(double a, double b) { return a > b ? a : b; }

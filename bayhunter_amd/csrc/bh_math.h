@@ -33,6 +33,7 @@ BH_DEV void bh_sincos_slow(double x, double *s, double *c) { ::sincos(x, s, c); 
 // tests/hostsim "exact" build: glibc's functions, so that the replay is bit-identical to the oracle
 BH_DEV void bh_sincos(double x, double *sn, double *cs) { *sn = std::sin(x); *cs = std::cos(x); }
 BH_DEV double bh_exp(double x) { return std::exp(x); }
+BH_DEV double bh_exp_bounded(double x) { return std::exp(x); }
 #else
 BH_DEV void bh_sincos(double x, double *sn, double *cs)
 {
@@ -101,6 +102,33 @@ BH_DEV double bh_exp(double x)
     p = bh_fma(p, r, 1.0);
     double res = bh_ldexp(p, (int)k);
     return (x != x) ? x : res;
+}
+
+// exp for arguments known to lie in [-700, 700] (the period equation only asks for exp(-2p), p < 16,
+// and exp(-exa), exa < 60): same reduction and polynomial as bh_exp without the range clamps.
+BH_DEV double bh_exp_bounded(double x)
+{
+    const double LOG2E = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double k = bh_rint(x * LOG2E);
+    double r = bh_fma(-k, LN2_HI, x);
+    r = bh_fma(-k, LN2_LO, r);
+    double p = 1.6059043836821613e-10;
+    p = bh_fma(p, r, 2.08767569878681e-09);
+    p = bh_fma(p, r, 2.505210838544172e-08);
+    p = bh_fma(p, r, 2.755731922398589e-07);
+    p = bh_fma(p, r, 2.7557319223985893e-06);
+    p = bh_fma(p, r, 2.48015873015873e-05);
+    p = bh_fma(p, r, 1.984126984126984e-04);
+    p = bh_fma(p, r, 1.3888888888888889e-03);
+    p = bh_fma(p, r, 8.333333333333333e-03);
+    p = bh_fma(p, r, 4.1666666666666664e-02);
+    p = bh_fma(p, r, 1.6666666666666666e-01);
+    p = bh_fma(p, r, 0.5);
+    p = bh_fma(p, r, 1.0);
+    p = bh_fma(p, r, 1.0);
+    return bh_ldexp(p, (int)k);
 }
 #endif
 

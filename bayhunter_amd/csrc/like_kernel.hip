@@ -319,7 +319,10 @@ __global__ void division_selftest_kernel(long n, unsigned seed, int max_exp, uns
         const double r1 = a / b, r2 = c / b;
         if (__double_as_longlong(q1) != __double_as_longlong(r1)) nbad++;
         if (__double_as_longlong(q2) != __double_as_longlong(r2)) nbad++;
+        const double sa = fabs(a);
+        if (__double_as_longlong(xsqrt(sa)) != __double_as_longlong(sqrt(sa))) nbad++;
     }
+    if (i == 0 && (xsqrt(0.0) != 0.0)) nbad++;
     if (nbad) atomicAdd(bad, nbad);
 }
 hipError_t launch_division_selftest(long n, unsigned seed, int max_exp, unsigned long long *bad, hipStream_t stream)

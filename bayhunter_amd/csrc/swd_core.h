@@ -40,7 +40,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
     } else {
         pex = p;
         fac = 0.0;
-        if (p < 16) fac = bh_exp(-2.0 * p);
+        if (p < 16) fac = bh_exp_bounded(-2.0 * p);
         cosp = (1.0 + fac) * 0.5;
         sinp = (1.0 - fac) * 0.5;
         w = xdiv(sinp, ra);
@@ -55,7 +55,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
     } else {
         sex = q;
         fac = 0.0;
-        if (q < 16) fac = bh_exp(-2.0 * q);
+        if (q < 16) fac = bh_exp_bounded(-2.0 * q);
         cosq = (1.0 + fac) * 0.5;
         sinq = (1.0 - fac) * 0.5;
         y = xdiv(sinq, rb);
@@ -63,7 +63,7 @@ BH_DEV void swd_var(double p, double q, double ra, double rb, double wvno, doubl
     }
     double exa = pex + sex;
     double a0 = 0.0;
-    if (exa < 60.0) a0 = bh_exp(-exa);
+    if (exa < 60.0) a0 = bh_exp_bounded(-exa);
     o.a0 = a0;
     o.cpcq = cosp * cosq; o.cpy = cosp * y; o.cpz = cosp * z;
     o.cqw = cosq * w;     o.cqx = cosq * x;
@@ -142,9 +142,9 @@ BH_DEV void swd_ray_layer_matrix(const Lay &lay, int i0, double wvno, double wvn
     double gammk = 2.0 * t * t;
     double gam = gammk * wvno2;
     double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
-    double ra = sqrt(wvnop * wvnom);
+    double ra = xsqrt(wvnop * wvnom);
     wvnop = wvno + xkb; wvnom = fabs(wvno - xkb);
-    double rb = sqrt(wvnop * wvnom);
+    double rb = xsqrt(wvnop * wvnom);
     double dpth = (double)lay.d(i0);
     double rho1 = (double)lay.rho(i0);
     double p = ra * dpth, q = rb * dpth, w, cosp;
@@ -222,7 +222,7 @@ BH_DEV void swd_love_layer(const Lay &lay, int i0, double wvno, double omega, Lo
     o.xmu = rho1 * beta1 * beta1;
     double xkb = xdiv(omega, beta1);
     double wvnop = wvno + xkb, wvnom = fabs(wvno - xkb);
-    double rb = sqrt(wvnop * wvnom);
+    double rb = xsqrt(wvnop * wvnom);
     double q = dm * rb, sinq, fac;
     if (wvno < xkb) {
         bh_sincos(q, &sinq, &o.cosq);
@@ -232,7 +232,7 @@ BH_DEV void swd_love_layer(const Lay &lay, int i0, double wvno, double omega, Lo
         o.cosq = 1.0; o.y = dm; o.z = 0.0;
     } else {
         fac = 0.0;
-        if (q < 16) fac = bh_exp(-2.0 * q);
+        if (q < 16) fac = bh_exp_bounded(-2.0 * q);
         o.cosq = (1.0 + fac) * 0.5;
         sinq = (1.0 - fac) * 0.5;
         o.y = xdiv(sinq, rb);
