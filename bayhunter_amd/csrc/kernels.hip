@@ -162,7 +162,8 @@ __global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A)
         __syncthreads();
         swd_team_assemble(lay, lane, SWD_T, tg.iwave, S, nt, trials, mats);
         __syncthreads();
-        swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
+        if (tg.iwave == 2 && nt <= 8) swd_team_chain_ray5(lay, lane, S, nt, trials, mats, dels);
+        else swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
         __syncthreads();
         swd_team_consume(S, nt, trials, dels);
         __syncthreads();

@@ -32,7 +32,7 @@ BH_DEV int swd_team_plan(const SwdState &S, int nlanes, double *trials)
     int cap = (nlm > 0) ? nlanes / nlm : SWD_TEAM_NT;
     if (cap < 1) cap = 1;
     if (cap > SWD_TEAM_NT) cap = SWD_TEAM_NT;
-    if (cap > nlanes) cap = nlanes;          // one chain lane per trial
+    if (cap > nlanes) cap = nlanes;          // one chain lane (or 8-lane group) per trial
     int nt = 1;
     trials[0] = S.ceval;
     if (S.st == SWD_ST_A || S.st == SWD_ST_B) {
@@ -122,6 +122,56 @@ BH_DEV void swd_team_chain(const Lay &lay, int lane, int ifunc, const SwdState &
         dels[lane] = (S.llw != 1) ? swd_ray_water(lay, wvno, omega, e) : e[0];
     }
 }
+
+#if !defined(BH_HOSTSIM)
+// Rayleigh chain with the 5 components of the Dunkin vector on 5 lanes (device only; the host
+// replay keeps swd_team_chain, whose arithmetic this reproduces operation for operation):
+// lanes 8j .. 8j+4 serve trial j.  Lane i forms ee_i = sum_k e_k*ca(k,i) in the reference's order
+// from its column of the layer matrix, the group max-reduces |ee_i| (normc), every lane divides its
+// own component with the shared reciprocal and the new vector is re-gathered by shuffles.
+// Requires nt <= 8 and all 64 lanes of the wave active.
+template <class Lay>
+__device__ __forceinline__ void swd_team_chain_ray5(const Lay &lay, int lane, const SwdState &S,
+                                                    int nt, const double *trials, const double *mats,
+                                                    double *dels)
+{
+    const int j = lane >> 3, i = lane & 7, gbase = lane & ~7;
+    const bool live = (j < nt) && (i < 5);
+    const int nlm = S.mmax - S.llw;
+    const double wvno = S.omega / trials[j < nt ? j : 0];
+    double omega = S.omega;
+    if (omega < 1.0e-4) omega = 1.0e-4;
+    double e[5];
+    swd_ray_halfspace(lay, S.mmax, wvno, wvno * wvno, omega, e);
+    // column i of ca as indices into the 19 stored values (swd_team_assemble's order):
+    // 0 c11 1 c12 2 c13 3 c14 4 c15 5 c21 6 c22 7 c23 8 c24 9 c31 10 c32 11 c33 12 c34 13 c35
+    // 14 c41 15 c42 16 c43 17 c51 18 c53 ; c25=c14 c44=c22 c45=c12 c52=c41 c54=c21 c55=c11
+    int k1, k2, k3, k4, k5;
+    switch (i) {
+    case 0: k1 = 0; k2 = 5; k3 = 9; k4 = 14; k5 = 17; break;
+    case 1: k1 = 1; k2 = 6; k3 = 10; k4 = 15; k5 = 14; break;
+    case 2: k1 = 2; k2 = 7; k3 = 11; k4 = 16; k5 = 18; break;
+    case 3: k1 = 3; k2 = 8; k3 = 12; k4 = 6; k5 = 5; break;
+    default: k1 = 4; k2 = 3; k3 = 13; k4 = 1; k5 = 0; break;
+    }
+    for (int r = nlm - 1; r >= 0; r--) {
+        const double *p = mats + ((long)(j < nt ? j : 0) * nlm + r) * SWD_NCA;
+        double ee = ((((0.0 + e[0] * p[k1]) + e[1] * p[k2]) + e[2] * p[k3]) + e[3] * p[k4]) + e[4] * p[k5];
+        double t1 = live ? fabs(ee) : 0.0;
+        t1 = dmax(t1, __shfl_xor(t1, 1, 64));
+        t1 = dmax(t1, __shfl_xor(t1, 2, 64));
+        t1 = dmax(t1, __shfl_xor(t1, 4, 64));
+        if (t1 < 1.e-40) t1 = 1.0;
+        const double en = qdiv(ee, recip_of(t1));
+        e[0] = __shfl(en, gbase + 0, 64);
+        e[1] = __shfl(en, gbase + 1, 64);
+        e[2] = __shfl(en, gbase + 2, 64);
+        e[3] = __shfl(en, gbase + 3, 64);
+        e[4] = __shfl(en, gbase + 4, 64);
+    }
+    if (j < nt && i == 0) dels[j] = (S.llw != 1) ? swd_ray_water(lay, wvno, omega, e) : e[0];
+}
+#endif
 
 // Feed the round's values to the search in order; stop at the first one that ends the scan.
 // Returns the number of values the reference would have computed (the rest was speculation).
