@@ -214,7 +214,8 @@ size_t bh_rf_workspace_bytes(int, int, const bh_rf_params *) { return 0; }
 static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vp,
                             const double *vs, const double *rho, const double *qp, const double *qs,
                             const bh_rf_params *par, double sigma, int depth_input, double *out,
-                            int out_stride, void *stream)
+                            int out_stride, void *stream, double *out_fz = nullptr,
+                            double *out_fr = nullptr)
 {
     if (!par) return fail_arg("par is NULL");
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
@@ -238,8 +239,9 @@ static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, 
     A.P.out_stride = out_stride;
     A.P.Lmax = Lmax;
     A.P.depth_input = depth_input;
-    A.P.M = pick_rf_M(B, Lmax, n);
-    if (bh::rf_lds_bytes(Lmax, n, 1) > 160 * 1024) return fail_arg("model does not fit LDS");
+    A.P.M = (out_fz && out_fr) ? 1 : pick_rf_M(B, Lmax, n);
+    if (bh::rf_lds_bytes(Lmax, n, 1, out_fz && out_fr) > 160 * 1024) return fail_arg("model does not fit LDS");
+    A.out_fz = out_fz; A.out_fr = out_fr;
     rc = get_twiddles(n, &A.tw);
     if (rc) return rc;
     A.B = B; A.mstride = model_stride; A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.qp = qp; A.qs = qs;
@@ -379,9 +381,7 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
              const double *rh, const double *qp, const double *qs, double *fz, double *fr, double *rf)
 {
     if (!z || !vp || !vs || !rh || !qp || !qs || !rf) return fail_arg("NULL pointer");
-    if (fz || fr)
-        return fail_arg("fz/fr (vertical/radial traces) are not produced; pass NULL "
-                        "(BayHunter discards them, rfmini_modrf.py:134-142)");
+    if ((fz == nullptr) != (fr == nullptr)) return fail_arg("pass both fz and fr, or neither");
     if (nlay < 1 || nlay > BH_MAX_LAYERS) return fail_arg("nlay out of range (max 100)");
     if (nsamp < 8 || nsamp > 4096) return fail_arg("nsamp out of range");
     int rc = ensure_device();
@@ -393,7 +393,8 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
         hb[4 * L + i] = qp[i]; hb[5 * L + i] = qs[i];
     }
     size_t off_out = hb.size() * sizeof(double);
-    size_t off_int = off_out + (size_t)nsamp * sizeof(double);
+    size_t off_zr = off_out + (size_t)nsamp * sizeof(double);
+    size_t off_int = off_zr + 2 * (size_t)nsamp * sizeof(double);
     rc = g_scratch.ensure(off_int + sizeof(int));
     if (rc) return rc;
     char *d = (char *)g_scratch.p;
@@ -405,10 +406,17 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
     par.nsamp = nsamp; par.waveno = waveno; par.nout = nsamp; par.out_off = 0;
     const double *dm = (const double *)d;
     rc = rf_launch_common(1, L, L, (const int *)(d + off_int), dm, dm + L, dm + 2 * L, dm + 3 * L,
-                          dm + 4 * L, dm + 5 * L, &par, sigma, 1, (double *)(d + off_out), nsamp, nullptr);
+                          dm + 4 * L, dm + 5 * L, &par, sigma, 1, (double *)(d + off_out), nsamp, nullptr,
+                          fz ? (double *)(d + off_zr) : nullptr,
+                          fz ? (double *)(d + off_zr) + nsamp : nullptr);
     if (rc) return rc;
     BH_HIP(hipDeviceSynchronize());
     BH_HIP(hipMemcpy(rf, d + off_out, (size_t)nsamp * sizeof(double), hipMemcpyDeviceToHost));
+    if (fz) {
+        BH_HIP(hipMemcpy(fz, d + off_zr, (size_t)nsamp * sizeof(double), hipMemcpyDeviceToHost));
+        BH_HIP(hipMemcpy(fr, d + off_zr + (size_t)nsamp * sizeof(double), (size_t)nsamp * sizeof(double),
+                         hipMemcpyDeviceToHost));
+    }
     return BH_OK;
 }
 

@@ -34,6 +34,7 @@ struct RfArgs {
     const double *h, *vp, *vs, *rho, *qp, *qs;
     const double *tw;  // FFT twiddles, rf_host.h
     double *out;
+    double *out_fz, *out_fr;  // optional [B][nsamp] vertical / radial traces (synrf_cwrap's fz, fr)
     RfLaunch P;
 };
 
@@ -74,6 +75,6 @@ hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream);
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream);
 hipError_t launch_swd_team(const SwdArgs &A, hipStream_t stream);
 hipError_t launch_rf(const RfArgs &A, hipStream_t stream);
-size_t rf_lds_bytes(int Lmax, int nsamp, int M);
+size_t rf_lds_bytes(int Lmax, int nsamp, int M, bool zr = false);
 
 }  // namespace bh

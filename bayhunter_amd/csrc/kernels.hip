@@ -171,7 +171,27 @@ __global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A)
 }
 
 // -------------------------------------------------------------------------------------------- RF
-// 3 waves per SIMD (<= 168 VGPRs, 8 spilled dwords): the recursion is latency-bound at 2
+// bit reversal (+ 1/sqrt(n)) and radix-2 butterflies of Mb buffers in LDS; all threads of the group
+__device__ __forceinline__ void rf_block_fft(double *S, int per_model, int Mb, int n, const RfLaunch &P,
+                                             const double *tw, int tid)
+{
+    for (int idx = tid; idx < Mb * n; idx += RF_T) {
+        int m = idx / n, i = idx - m * n;
+        rf_fft_bitrev_scale(S + (long)m * per_model, n, P.log2n, P.sc, i);
+    }
+    __syncthreads();
+    for (int l = 1; l < n; l <<= 1) {
+        for (int idx = tid; idx < Mb * (n / 2); idx += RF_T) {
+            int m = idx / (n / 2), bf = idx - m * (n / 2);
+            rf_fft_butterfly(S + (long)m * per_model, tw, l, bf);
+        }
+        __syncthreads();
+    }
+}
+
+// 3 waves per SIMD (<= 168 VGPRs, a few spilled dwords): the recursion is latency-bound at 2.
+// ZR: also keep the filtered vertical/radial spectra and return their traces (synrf_cwrap's fz, fr).
+template <bool ZR>
 __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) void rf_kernel(RfArgs A)
 {
     extern __shared__ double S[];
@@ -182,6 +202,7 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     const int L = P.Lmax;
     const RfLayout lo = rf_layout(L, P.nsamp);
     const int n = P.nsamp;
+    const int pm = lo.per_model + (ZR ? 4 * P.nfreq : 0);   // ZR: [spec_r | spec_z] behind the block
 
     // P1: flatten layers
     for (int idx = tid; idx < Mb * L; idx += RF_T) {
@@ -190,7 +211,7 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         if (i < nl)
-            rf_phase1_layer(S + (long)m * lo.per_model, lo, nl, i, A.h + b * A.mstride,
+            rf_phase1_layer(S + (long)m * pm, lo, nl, i, A.h + b * A.mstride,
                             A.vp + b * A.mstride, A.vs + b * A.mstride, A.rho + b * A.mstride,
                             A.qp ? A.qp + b * L : nullptr,
                             A.qs ? A.qs + b * L : nullptr, P.depth_input);
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         if (i < nl)
-            rf_phase2_interface(S + (long)m * lo.per_model, lo, P, nl, i, A.vp[b * A.mstride],
+            rf_phase2_interface(S + (long)m * pm, lo, P, nl, i, A.vp[b * A.mstride],
                                 A.vs[b * A.mstride]);
     }
     __syncthreads();
@@ -213,33 +234,46 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         int m = task / P.nfreq, j = task - m * P.nfreq;
         int nl = A.nlay[b0 + m];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
-        double *Sm = S + (long)m * lo.per_model;
-        cd crf = rf_phase3_task(Sm, lo, P, nl, j);
-        st_cd(Sm + 2 * j, crf);
+        double *Sm = S + (long)m * pm;
+        if (ZR) {
+            cd zr_r, zr_z;
+            cd crf = rf_phase3_task(Sm, lo, P, nl, j, &zr_r, &zr_z);
+            st_cd(Sm + 2 * j, crf);
+            st_cd(Sm + lo.per_model + 2 * j, zr_r);
+            st_cd(Sm + lo.per_model + 2 * P.nfreq + 2 * j, zr_z);
+        } else {
+            cd crf = rf_phase3_task(Sm, lo, P, nl, j);
+            st_cd(Sm + 2 * j, crf);
+        }
     }
     __syncthreads();
-    // P4: inverse FFT in LDS
+    // P4: inverse FFT in LDS (iftr, greens.cpp:136-158)
     const int nh = n / 2 - 1;
     for (int idx = tid; idx < Mb * nh; idx += RF_T) {
         int m = idx / nh, i = n / 2 + 1 + (idx - m * nh);
-        rf_fft_hermitian(S + (long)m * lo.per_model, n, i);
+        rf_fft_hermitian(S + (long)m * pm, n, i);
     }
     __syncthreads();
-    for (int idx = tid; idx < Mb * n; idx += RF_T) {
-        int m = idx / n, i = idx - m * n;
-        rf_fft_bitrev_scale(S + (long)m * lo.per_model, n, P.log2n, P.sc, i);
-    }
-    __syncthreads();
-    for (int l = 1; l < n; l <<= 1) {
-        for (int idx = tid; idx < Mb * (n / 2); idx += RF_T) {
-            int m = idx / (n / 2), bf = idx - m * (n / 2);
-            rf_fft_butterfly(S + (long)m * lo.per_model, A.tw, l, bf);
-        }
-        __syncthreads();
-    }
+    rf_block_fft(S, pm, Mb, n, P, A.tw, tid);
     for (int idx = tid; idx < Mb * P.nout; idx += RF_T) {
         int m = idx / P.nout, i = idx - m * P.nout;
-        A.out[(long)(b0 + m) * P.out_stride + P.out_off + i] = P.qn * S[(long)m * lo.per_model + 2 * i];
+        A.out[(long)(b0 + m) * P.out_stride + P.out_off + i] = P.qn * S[(long)m * pm + 2 * i];
+    }
+    if (ZR) {   // iftr2 (greens.cpp:161-194): one FFT of cx = radial + i*vertical
+        __syncthreads();
+        for (int idx = tid; idx < Mb * n; idx += RF_T) {
+            int m = idx / n, i = idx - m * n;
+            double *Sm = S + (long)m * pm;
+            st_cd(Sm + 2 * i, rf_fft_pair_entry(Sm + lo.per_model, Sm + lo.per_model + 2 * P.nfreq, n, i));
+        }
+        __syncthreads();
+        rf_block_fft(S, pm, Mb, n, P, A.tw, tid);
+        for (int idx = tid; idx < Mb * n; idx += RF_T) {
+            int m = idx / n, i = idx - m * n;
+            const double *Sm = S + (long)m * pm;
+            A.out_fr[(long)(b0 + m) * n + i] = P.qn * Sm[2 * i];
+            A.out_fz[(long)(b0 + m) * n + i] = P.qn * Sm[2 * i + 1];
+        }
     }
 }
 
@@ -278,24 +312,26 @@ hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
     return hipGetLastError();
 }
 
-size_t rf_lds_bytes(int Lmax, int nsamp, int M)
+size_t rf_lds_bytes(int Lmax, int nsamp, int M, bool zr)
 {
     RfLayout lo = rf_layout(Lmax, nsamp);
-    return (size_t)M * lo.per_model * sizeof(double);
+    return (size_t)M * (lo.per_model + (zr ? 4 * (nsamp / 2 + 1) : 0)) * sizeof(double);
 }
 
 hipError_t launch_rf(const RfArgs &A, hipStream_t stream)
 {
-    size_t lds = rf_lds_bytes(A.P.Lmax, A.P.nsamp, A.P.M);
-    static thread_local size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)rf_kernel,
+    const bool zr = A.out_fz != nullptr && A.out_fr != nullptr;
+    size_t lds = rf_lds_bytes(A.P.Lmax, A.P.nsamp, A.P.M, zr);
+    static thread_local size_t lds_set[2] = {0, 0};
+    if (lds > 48 * 1024 && lds > lds_set[zr]) {
+        hipError_t e = hipFuncSetAttribute(zr ? (const void *)rf_kernel<true> : (const void *)rf_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_set = lds;
+        lds_set[zr] = lds;
     }
     dim3 grid((A.B + A.P.M - 1) / A.P.M);
-    hipLaunchKernelGGL(rf_kernel, grid, dim3(RF_T), lds, stream, A);
+    if (zr) hipLaunchKernelGGL(rf_kernel<true>, grid, dim3(RF_T), lds, stream, A);
+    else hipLaunchKernelGGL(rf_kernel<false>, grid, dim3(RF_T), lds, stream, A);
     return hipGetLastError();
 }
 

@@ -252,7 +252,8 @@ BH_DEV void rf_phase2_interface(double *S, const RfLayout &lo, const RfLaunch &P
 #if !defined(BH_HOSTSIM)
 #pragma clang fp contract(fast)
 #endif
-BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j)
+BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j,
+                         cd *zr_r = nullptr, cd *zr_z = nullptr)
 {
     const double *par = S + lo.off_par;
     const double *coef = S + lo.off_coef;
@@ -306,12 +307,14 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
         cz = cx;
         cr = cy;
     }
+    const cd arr_r = cr, arr_z = cz;                              // the cr[] / cz[] arrays of compute_rf
     if (P.waveno == 1) { cd tmp = cz; cz = cr; cr = tmp; }        // greens.cpp:369-373
     double denom = cz.re * cz.re + cz.im * cz.im;                 // real(cz*conj(cz)); no water level
     cd crf = (cr * conj(cz)) / denom;
     double wa = w / P.gauss;
     wa = (wa > 50.0) ? 50.0 : wa;
     cd cq = cexp_(mk(-0.25 * (wa * wa), -w * P.tshift)) * P.qgauss;
+    if (zr_r) { *zr_r = arr_r * cq; *zr_z = arr_z * cq; }       // greens.cpp:393-394 (for iftr2)
     return crf * cq;
 }
 
@@ -341,6 +344,13 @@ BH_DEV void rf_fft_bitrev_scale(double *X, int n, int log2n, double sc, int i)
     st_cd(X + 2 * j, xi * sc);
     st_cd(X + 2 * i, xj * sc);
     (void)n;
+}
+// iftr2 (greens.cpp:161-194): entry i of cx = cx1 + i*cx2 built from the two half spectra
+BH_DEV cd rf_fft_pair_entry(const double *spec_r, const double *spec_z, int n, int i)
+{
+    cd c1 = (i <= n / 2) ? ld_cd(spec_r + 2 * i) : conj(ld_cd(spec_r + 2 * (n - i)));
+    cd c2 = (i <= n / 2) ? ld_cd(spec_z + 2 * i) : conj(ld_cd(spec_z + 2 * (n - i)));
+    return c1 + mk(0., 1.) * c2;
 }
 // butterfly number bf (0 .. n/2-1) of the stage with half-span l; tw[l+m] = exp(i*pi*m/l)
 BH_DEV void rf_fft_butterfly(double *X, const double *tw, int l, int bf)

@@ -166,7 +166,8 @@ int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, cons
 int bh_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
                   int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
                   const double *t, double *cg, int *err);
-/* Same argument list as synrf_cwrap (wrap.cpp:57-63).  fz/fr may be NULL. Returns BH_OK, not 1. */
+/* Same argument list as synrf_cwrap (wrap.cpp:57-63).  fz and fr (vertical / radial traces, which
+ * BayHunter discards, rfmini_modrf.py:134-142) may both be NULL.  Returns BH_OK, not 1. */
 int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double nsv, double sigma,
              int waveno, int nlay, const double *z, const double *vp, const double *vs,
              const double *rh, const double *qp, const double *qs,

@@ -367,3 +367,27 @@ def test_division_selftest(lib):
         bad = C.c_long(-1)
         _lib.check(lib.bh_selftest_division(n, 12345 + max_exp, max_exp, C.byref(bad)))
         assert bad.value == 0, (max_exp, bad.value)
+
+
+def test_synrf_dropin_returns_all_three_traces(lib, oracle):
+    """bh_synrf with fz/fr buffers = the full return value of rfmini.synrf (fz, fr, rf), P and SV."""
+    from bayhunter_amd import _lib
+    H, VP, VS, RHO, nl = draw_models(4, (3, 9), seed=17, sorted_vs=False)
+    for b in range(4):
+        n = nl[b]
+        z = np.ascontiguousarray(np.concatenate(([0], np.cumsum(H[b, :n])[:-1])))
+        vp, vs, rh = (np.ascontiguousarray(a[b, :n]) for a in (VP, VS, RHO))
+        qp, qs = np.full(n, 450.), np.full(n, 200.)
+        for wn, nsamp in ((0, 512), (1, 256)):
+            want = oracle.synrf(z, vp, vs, rh, qp, qs, 6.4, 1.5, nsamp, 5.0, 5.0, 3.1, 0.27, wn)
+            fz, fr, rf = np.zeros(nsamp), np.zeros(nsamp), np.zeros(nsamp)
+            _lib.check(lib.bh_synrf(nsamp, 5.0, 5.0, 6.4, 1.5, 3.1, 0.27, wn, n, z.ctypes.data,
+                                    vp.ctypes.data, vs.ctypes.data, rh.ctypes.data, qp.ctypes.data,
+                                    qs.ctypes.data, fz.ctypes.data, fr.ctypes.data, rf.ctypes.data))
+            for got, w in zip((fz, fr, rf), want):
+                assert np.abs(got - w).max() <= TOL_RF * max(1.0, np.abs(w).max())
+            rf2 = np.zeros(nsamp)
+            _lib.check(lib.bh_synrf(nsamp, 5.0, 5.0, 6.4, 1.5, 3.1, 0.27, wn, n, z.ctypes.data,
+                                    vp.ctypes.data, vs.ctypes.data, rh.ctypes.data, qp.ctypes.data,
+                                    qs.ctypes.data, None, None, rf2.ctypes.data))
+            assert np.array_equal(rf, rf2)
