@@ -325,8 +325,12 @@ namespace {
 struct Scratch {  // per-thread device scratch for the synchronous single-model calls
     void *p = nullptr;
     size_t n = 0;
+    int dev = -1;
     int ensure(size_t bytes)
     {
+        int cur = 0;
+        BH_HIP(hipGetDevice(&cur));
+        if (cur != dev) { p = nullptr; n = 0; dev = cur; }   // buffer of another device: leave it be
         if (bytes <= n) return BH_OK;
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;

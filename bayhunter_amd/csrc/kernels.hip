@@ -18,6 +18,22 @@
 
 namespace bh {
 
+// hipFuncSetAttribute is per device: remember the largest dynamic-LDS size set per (kernel, device)
+static hipError_t ensure_dyn_lds(const void *func, size_t lds, size_t (&set)[16])
+{
+    if (lds <= 48 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 15;
+    if (lds > set[dev]) {
+        e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        set[dev] = lds;
+    }
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------------- SWD
 struct LdsLay {
     float *base;  // lds + lane
@@ -282,6 +298,9 @@ hipError_t launch_swd_team(const SwdArgs &A, hipStream_t stream)
 {
     size_t lds = (size_t)swd_team_lds_doubles(A.Lmax, SWD_T) * sizeof(double) +
                  (size_t)4 * A.Lmax * sizeof(float);
+    static size_t lds_set[16] = {0};
+    hipError_t e = ensure_dyn_lds((const void *)swd_team_kernel, lds, lds_set);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(swd_team_kernel, dim3(A.B, A.ntargets), dim3(SWD_T), lds, stream, A);
     return hipGetLastError();
 }
@@ -289,13 +308,9 @@ hipError_t launch_swd_team(const SwdArgs &A, hipStream_t stream)
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
 {
     size_t lds = (size_t)4 * A.Lmax * SWD_T * sizeof(float);
-    static thread_local size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)swd_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_set = lds;
-    }
+    static size_t lds_set[16] = {0};
+    hipError_t e0 = ensure_dyn_lds((const void *)swd_kernel, lds, lds_set);
+    if (e0 != hipSuccess) return e0;
     // persistent lanes: no more waves than the chip keeps resident (the queue feeds them), no more
     // than there are models
     // The queue pays once a lane runs >= 3 searches: it removes the 15 % lost to lanes idling until
@@ -322,13 +337,10 @@ hipError_t launch_rf(const RfArgs &A, hipStream_t stream)
 {
     const bool zr = A.out_fz != nullptr && A.out_fr != nullptr;
     size_t lds = rf_lds_bytes(A.P.Lmax, A.P.nsamp, A.P.M, zr);
-    static thread_local size_t lds_set[2] = {0, 0};
-    if (lds > 48 * 1024 && lds > lds_set[zr]) {
-        hipError_t e = hipFuncSetAttribute(zr ? (const void *)rf_kernel<true> : (const void *)rf_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_set[zr] = lds;
-    }
+    static size_t lds_set[2][16] = {{0}, {0}};
+    hipError_t e = ensure_dyn_lds(zr ? (const void *)rf_kernel<true> : (const void *)rf_kernel<false>, lds,
+                                  lds_set[zr]);
+    if (e != hipSuccess) return e;
     dim3 grid((A.B + A.P.M - 1) / A.P.M);
     if (zr) hipLaunchKernelGGL(rf_kernel<true>, grid, dim3(RF_T), lds, stream, A);
     else hipLaunchKernelGGL(rf_kernel<false>, grid, dim3(RF_T), lds, stream, A);

@@ -353,12 +353,17 @@ hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
             }
     }
     size_t lds = (size_t)LIKE_M * nmax * sizeof(double);
-    static thread_local size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)like_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t lds_set[16] = {0};
+    if (lds > 48 * 1024) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        lds_set = lds;
+        dev &= 15;
+        if (lds > lds_set[dev]) {
+            e = hipFuncSetAttribute((const void *)like_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_set[dev] = lds;
+        }
     }
     dim3 grid((A.B + LIKE_M - 1) / LIKE_M);
     hipLaunchKernelGGL(like_kernel, grid, dim3(LIKE_T), lds, stream, A);

@@ -1,0 +1,47 @@
+/* consumer.c -- a plain C99 client of libbayhunter_amd.so (tests/test_c_abi.py).
+ * Proves that include/bayhunter_amd.h is a C header (no C++, no HIP, no torch types) and that the
+ * two drop-in entry points are callable from the language a cgo/JNI/FFI stub would use.
+ * usage: consumer            -> version + argument validation only (no GPU needed)
+ *        consumer run        -> tutorial model through bh_surfdisp96 and bh_synrf, values on stdout */
+#include <stdio.h>
+#include <string.h>
+#include "bayhunter_amd.h"
+
+int main(int argc, char **argv)
+{
+    int ndev = -1, err = -1, rc, k;
+    printf("%s\n", bh_version());
+    if (bh_device_count(&ndev) != BH_OK) return 2;
+    printf("devices %d\n", ndev);
+    {   /* argument validation happens before any device work */
+        float m[4] = {5.f, 23.f, 8.f, 0.f};
+        double t[1] = {1.0}, cg[1];
+        rc = bh_surfdisp96(m, m, m, m, 101, 0, 2, 1, 0, 1, t, cg, &err);
+        if (rc != BH_ERR_ARG) { printf("expected BH_ERR_ARG, got %d\n", rc); return 3; }
+        printf("arg check ok: %s\n", bh_last_error());
+    }
+    if (argc > 1 && strcmp(argv[1], "run") == 0) {
+        /* tutorial model st3 (tutorial/create_testdata.py:13-17), vp = 1.73 vs, rho = .77 + .32 vp */
+        float h[4] = {5.f, 23.f, 8.f, 0.f}, vs[4] = {2.7f, 3.6f, 3.8f, 4.4f}, vp[4], rho[4];
+        double hd[4], vsd[4] = {2.7, 3.6, 3.8, 4.4}, vpd[4], rhod[4], z[4] = {0., 5., 28., 36.};
+        double qp[4] = {500., 500., 500., 500.}, qs[4] = {225., 225., 225., 225.};
+        double per[21], cg[21], rf[512];
+        for (k = 0; k < 4; k++) {
+            vpd[k] = vsd[k] * 1.73; rhod[k] = vpd[k] * 0.32 + 0.77; hd[k] = h[k];
+            vp[k] = (float)vpd[k]; rho[k] = (float)rhod[k];
+        }
+        for (k = 0; k < 21; k++) per[k] = 1.0 + 2.0 * k;
+        rc = bh_surfdisp96(h, vp, vs, rho, 4, 0, 2, 1, 0, 21, per, cg, &err);
+        if (rc != BH_OK) { printf("bh_surfdisp96 failed: %s\n", bh_last_error()); return 4; }
+        printf("err %d\n", err);
+        for (k = 0; k < 21; k++) printf("cg %.17g\n", cg[k]);
+        {
+            double nsvp = vpd[0], nsvs = vsd[0], kk = nsvp / nsvs, sigma = (2 - kk * kk) / (2 - 2 * kk * kk);
+            rc = bh_synrf(512, 5.0, 5.0, 6.4, 1.0, nsvs, sigma, 0, 4, z, vpd, vsd, rhod, qp, qs, NULL, NULL, rf);
+        }
+        if (rc != BH_OK) { printf("bh_synrf failed: %s\n", bh_last_error()); return 5; }
+        for (k = 0; k < 201; k++) printf("rf %.17g\n", rf[k]);
+        (void)hd;
+    }
+    return 0;
+}
