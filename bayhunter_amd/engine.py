@@ -11,6 +11,8 @@ import torch
 
 from . import _lib
 
+RAGGED_SORT_MIN = 8192   # below this the team kernel runs (one wave per model): order is irrelevant
+
 SWD_REFS = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
 RF_REFS = {'prf': 0, 'seis': 0, 'srf': 1}
 
@@ -30,11 +32,14 @@ class DeviceModels(object):
     """A batch of layered models resident in HBM: `packed` is [B, 4, Lmax] fp64 (h, vp, vs, rho
     rows of each model contiguous, zero padded), `nlay` int32 [B].  H/VP/VS/RHO are views."""
 
-    def __init__(self, packed, nlay):
+    def __init__(self, packed, nlay, inv=None):
         assert packed.dim() == 3 and packed.shape[1] == 4 and packed.is_contiguous()
         self.packed, self.nlay = packed, nlay
         self.B, self.Lmax = packed.shape[0], packed.shape[2]
         self.H, self.VP, self.VS, self.RHO = (packed[:, i, :] for i in range(4))
+        # When the batch was re-ordered at upload (ragged layer counts), row i of the caller's arrays
+        # sits at row inv[i] here; ForwardEngine.run hands results back in the caller's order.
+        self.inv = inv
 
 
 class SwdSpec(object):
@@ -107,6 +112,7 @@ class ForwardEngine(object):
         self._ws = None
         self._side = None        # side stream: RF back-fills the SIMDs the SWD tail leaves idle
         self.overlap = True
+        self.sort_ragged = True  # re-order ragged batches by layer count at upload
 
     # -- helpers
     def _as_dev(self, x, dtype):
@@ -122,7 +128,19 @@ class ForwardEngine(object):
         work queue."""
         f64 = torch.float64
         parts = [self._as_dev(x, f64) for x in (H, VP, VS, RHO)]
-        return DeviceModels(torch.stack(parts, dim=1).contiguous(), self._as_dev(nlay, torch.int32))
+        packed = torch.stack(parts, dim=1).contiguous()
+        nlay = self._as_dev(nlay, torch.int32)
+        inv = None
+        if self.sort_ragged and packed.shape[0] > RAGGED_SORT_MIN:
+            lo, hi = torch.aminmax(nlay)
+            if int(lo) != int(hi):
+                # lanes of a wave loop over their models' layers in lock step: deepest models first
+                # (similar depths share a wave, and the long searches do not end up as the tail)
+                perm = torch.argsort(nlay, descending=True, stable=True)
+                packed, nlay = packed[perm].contiguous(), nlay[perm].contiguous()
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        return DeviceModels(packed, nlay, inv)
 
     def alloc_out(self, B):
         out = torch.empty((B, self.row), dtype=torch.float64, device=self.device)
@@ -139,7 +157,8 @@ class ForwardEngine(object):
         H, VP, VS, RHO, nlay = models.H, models.VP, models.VS, models.RHO, models.nlay
         B, Lmax = models.B, models.Lmax
         mstride = 4 * Lmax
-        if out is None or err is None:
+        user_out, user_err = out, err
+        if out is None or err is None or models.inv is not None:
             out, err = self.alloc_out(B)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         sp = C.c_void_p(st.cuda_stream)
@@ -175,4 +194,11 @@ class ForwardEngine(object):
                 st.wait_stream(side)
                 for t in (H, VP, VS, RHO, nlay, out):
                     t.record_stream(side)
+            if models.inv is not None:       # back to the caller's row order
+                if user_out is not None and user_err is not None:
+                    torch.index_select(out, 0, models.inv, out=user_out)
+                    torch.index_select(err, 0, models.inv, out=user_err)
+                    out, err = user_out, user_err
+                else:
+                    out, err = out.index_select(0, models.inv), err.index_select(0, models.inv)
         return out, err

@@ -391,3 +391,28 @@ def test_synrf_dropin_returns_all_three_traces(lib, oracle):
                                     vp.ctypes.data, vs.ctypes.data, rh.ctypes.data, qp.ctypes.data,
                                     qs.ctypes.data, None, None, rf2.ctypes.data))
             assert np.array_equal(rf, rf2)
+
+
+def test_ragged_batch_is_reordered_transparently(lib, oracle):
+    """Above 8192 models a ragged batch is sorted by layer count at upload; results come back in the
+    caller's order, identical to the unsorted run, with and without caller-provided buffers."""
+    import torch
+    from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
+    H, VP, VS, RHO, nl = draw_models(9000, (2, 12), seed=41, sorted_vs=False)
+    per = np.linspace(1, 41, 11)
+    eng = ForwardEngine(swd=[SwdSpec('rdispph', per)], rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
+    models = eng.upload(H, VP, VS, RHO, nl)
+    assert models.inv is not None
+    out, err = eng.run(models)
+    buf_out, buf_err = eng.alloc_out(9000)
+    eng.run(models, out=buf_out, err=buf_err)
+    eng.sort_ragged = False
+    ref_out, ref_err = eng.run(H, VP, VS, RHO, nl)
+    torch.cuda.synchronize()
+    for o, e in ((out, err), (buf_out, buf_err)):
+        assert torch.equal(o.nan_to_num(nan=-1.0), ref_out.nan_to_num(nan=-1.0)) and torch.equal(e, ref_err)
+    sl = slice(100, 132)
+    want, werr, _ = oracle.swd_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl], per, 2, 0)
+    assert np.array_equal(err.cpu().numpy()[sl, 0], werr)
+    ok = werr == 0
+    assert np.abs(out.cpu().numpy()[sl][ok][:, :11] - want[ok]).max() <= TOL_PHASE
