@@ -82,6 +82,8 @@ def main():
     q = ctx.Queue()
     sessions = [broker.session() for _ in range(nclients)]
     procs = [ctx.Process(target=chain, args=(i, sessions[i], niter, q)) for i in range(nclients)]
+    import time
+    t0 = time.perf_counter()
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in procs)
@@ -95,7 +97,9 @@ def main():
     broker.stop()
     np.savez(out, likes=np.stack([res[i] for i in range(nclients)]), launches=st['launches'],
              models=st['models'], mean_batch=st['mean_batch'])
-    print('broker stats', st)
+    wall = time.perf_counter() - t0
+    print('broker stats', st, '| %d chains x %d iterations in %.2f s = %.0f iterations/s (%.2f ms per launch)'
+          % (nclients, niter, wall, nclients * niter / wall, 1e3 * st['busy_s'] / max(1, st['launches'])))
 
 
 if __name__ == '__main__':
