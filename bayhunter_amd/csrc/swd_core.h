@@ -297,6 +297,14 @@ BH_DEV float swd_gtsolh(float a, float b)
     return c;
 }
 
+// real*4 ** real*4 (surfdisp96.f:547): glibc's powf is correctly rounded but for rare near-ties, so
+// the device evaluates in fp64 and rounds once; the host replay uses powf itself.
+#if defined(BH_HOSTSIM)
+BH_DEV float swd_powf(float x, float y) { return powf(x, y); }
+#else
+BH_DEV float swd_powf(float x, float y) { return (float)::pow((double)x, (double)y); }
+#endif
+
 // sphere, surfdisp96.f:486-553, both calls (iflag 0 then iflag 1 for this lane's wave type) folded
 // into one pass: d,a,b are transformed, rho is scaled by btp**(-5) (Love) / btp**(-2.275) (Rayleigh).
 template <class Lay>
@@ -318,7 +326,7 @@ BH_DEV void swd_sphere(Lay &lay, int mmax, int ifunc)
             float x2 = btp * btp, x4 = x2 * x2, x5 = x4 * btp;
             lay.set_rho(i, rtp * (1.0f / x5));
         } else {
-            lay.set_rho(i, rtp * powf(btp, -2.275f));
+            lay.set_rho(i, rtp * swd_powf(btp, -2.275f));
         }
         r0 = r1;
     }
