@@ -111,7 +111,7 @@ def cpu_baseline(wl_name, per_core=None):
 
 
 def measured_traffic(kernel, workload, B):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json,
+    """PMC record of `kernel` (HBM bytes per launch, VALU busy, lane utilisation) from the committed passes (profiles/*_traffic.json,
     FETCH_SIZE doubled + WRITE_SIZE, separate --pmc runs), if one was taken at this configuration;
     bench.py itself cannot collect PMC counters."""
     import glob
@@ -125,7 +125,7 @@ def measured_traffic(kernel, workload, B):
         wl_ok = ('--workload ' + workload) in cfg or (workload == 'joint10' and '--workload' not in cfg)
         b_ok = ('--batch %d' % B) in cfg or ('--batch' not in cfg and B == WORKLOADS[workload]['B'])
         if wl_ok and b_ok and kernel in d.get('kernels', {}):
-            best = d['kernels'][kernel]['hbm_bytes']
+            best = d['kernels'][kernel]
     return best
 
 
@@ -251,7 +251,8 @@ def main():
         dom_bytes = (bytes_swd if dom_is_swd else bytes_rf) * B
         dom_flop = (flop_swd if dom_is_swd else flop_rf) * B
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = measured_traffic('swd_kernel' if dom_is_swd else 'rf_kernel', args.workload, B)
+        pmc = measured_traffic('swd_kernel' if dom_is_swd else 'rf_kernel', args.workload, B) or {}
+        traffic = pmc.get('hbm_bytes')
         value = world * B * args.steps / dt
         res = {
             "metric": "forward evals/sec (SWD+RF, 10-layer)" if args.workload == 'joint10'
@@ -276,7 +277,9 @@ def main():
                           "unit": "TFLOP/s",
                           "frac": dom_flop / (dom_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                           "flop_per_eval_reference_path": flop_swd + flop_rf,
-                          "n_dltar_per_eval": counts},
+                          "n_dltar_per_eval": counts,
+                          "valu_pipes_busy_pmc": pmc.get('valu_busy'),
+                          "lane_utilisation_pmc": pmc.get('lane_utilisation')},
             "kernels_ms": {"swd_kernel": ms_swd, "rf_kernel": ms_rf,
                            "note": "serialised; in the timed steps rf_kernel runs on a second stream and back-fills the tail of swd_kernel"},
             "cpu_baseline": cpu,

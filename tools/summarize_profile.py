@@ -18,7 +18,8 @@ def main(tag, src=None):
     src = src or os.path.join(root, 'gpurun_out', 'prof_' + tag)
     dst = os.path.join(root, 'profiles')
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(src + '/trace/*/*_kernel_stats.csv')[0]
+    newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+    stats = newest(src + '/trace/*/*_kernel_stats.csv')
     shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
     cfgf = os.path.join(src, 'config.txt')
     cfg = open(cfgf).read().strip() if os.path.exists(cfgf) else ''
@@ -27,7 +28,7 @@ def main(tag, src=None):
         f = glob.glob(src + '/' + p + '/*/*_counter_collection.csv')
         if not f:
             continue
-        for r in csv.DictReader(open(f[0])):
+        for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
             k = r['Kernel_Name'].split('(')[0]
             if 'bh::' in k:
                 pmc[k][r['Counter_Name']].append(float(r['Counter_Value']))
@@ -40,7 +41,15 @@ def main(tag, src=None):
     traffic = {}
     for k, d in avg.items():
         if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+            # VALU pipes busy: SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; a dispatch
+            # lasts GRBM_GUI_ACTIVE/8 cycles (the counter is summed over the 8 XCDs) on 1024 SIMDs
+            busy = None
+            if 'SQ_ACTIVE_INST_VALU' in d and 'GRBM_GUI_ACTIVE' in d:
+                busy = d['SQ_ACTIVE_INST_VALU'] * 4.0 / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0)
             traffic[k.replace('bh::', '')] = {
+                'valu_busy': busy,
+                'lane_utilisation': (d['SQ_THREAD_CYCLES_VALU'] / (64 * d['SQ_ACTIVE_INST_VALU'])
+                                     if 'SQ_THREAD_CYCLES_VALU' in d else None),
                 'read_bytes': 2.0 * d['FETCH_SIZE'] * 1024, 'write_bytes': d['WRITE_SIZE'] * 1024,
                 'hbm_bytes': 2.0 * d['FETCH_SIZE'] * 1024 + d['WRITE_SIZE'] * 1024,
                 'avg_ms_rocprof': dur.get(k)}
@@ -65,6 +74,9 @@ def main(tag, src=None):
                           % (k, d['SQ_THREAD_CYCLES_VALU'] / (64 * d['SQ_ACTIVE_INST_VALU']),
                              d.get('SQ_ACTIVE_INST_ANY', float('nan')) / d['SQ_WAVE_CYCLES']))
         for k, t in traffic.items():
+            if t.get('valu_busy') is not None:
+                out.write('* %s: VALU pipes busy %.0f %% of the dispatch (SQ_ACTIVE_INST_VALU*4 / '
+                          '(GRBM_GUI_ACTIVE/8 * 1024 SIMDs))\n' % (k, 100 * t['valu_busy']))
             out.write('* %s: HBM read %.1f MB (2 x FETCH_SIZE), written %.1f MB per launch\n'
                       % (k, t['read_bytes'] / 1e6, t['write_bytes'] / 1e6))
     print(open(os.path.join(dst, tag + '_rocprofv3_summary.md')).read())
