@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
-SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip"]
+SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip", "chains.cpp"]
 HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "swd_team.h", "rf_core.h", "rf_host.h", "kernels.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
@@ -75,8 +75,43 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+class ChainConfig(C.Structure):
+    """struct bh_chain_config (priors and initparams of the reference, src/defaults/defaults.ini)."""
+    _fields_ = [("ntargets", C.c_int), ("layers_min", C.c_int), ("layers_max", C.c_int),
+                ("vs_min", C.c_double), ("vs_max", C.c_double), ("z_min", C.c_double), ("z_max", C.c_double),
+                ("vpvs_fixed", C.c_int), ("vpvs_min", C.c_double), ("vpvs_max", C.c_double),
+                ("has_mantle", C.c_int), ("mantle_vs", C.c_double), ("mantle_vpvs", C.c_double),
+                ("has_mohoest", C.c_int), ("moho_mean", C.c_double), ("moho_std", C.c_double),
+                ("thickmin", C.c_double), ("has_lvz", C.c_int), ("has_hvz", C.c_int),
+                ("lvz", C.c_double), ("hvz", C.c_double), ("propdist", C.c_double * 5),
+                ("acceptance", C.c_double * 2), ("iter_burnin", C.c_long), ("iter_main", C.c_long),
+                ("noise_fixed", C.c_int * (2 * MAX_TARGETS)), ("noise_lo", C.c_double * (2 * MAX_TARGETS)),
+                ("noise_hi", C.c_double * (2 * MAX_TARGETS))]
+
+
+class ChainStorage(C.Structure):
+    """struct bh_chain_storage: caller-owned float32 sample arrays (src/mcmcOptimizer.py:77-125)."""
+    _fields_ = [("nmodels", C.c_long), ("models", C.c_void_p), ("misfits", C.c_void_p),
+                ("likes", C.c_void_p), ("noise", C.c_void_p), ("vpvs", C.c_void_p), ("iter", C.c_void_p)]
+
+
 _vp = C.c_void_p
 _SIGS = {
+    "bh_chains_create": (C.c_int, [C.POINTER(ChainConfig), C.c_int, _vp, C.POINTER(ChainStorage),
+                                   C.POINTER(_vp)]),
+    "bh_chains_destroy": (None, [_vp]),
+    "bh_chains_set_threads": (C.c_int, [_vp, C.c_int]),
+    "bh_chains_propose": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
+    "bh_chains_accept": (C.c_int, [_vp, _vp, _vp]),
+    "bh_chains_done": (C.c_int, [_vp]),
+    "bh_chains_iteration": (C.c_long, [_vp]),
+    "bh_chains_counters": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "bh_chains_current": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), _vp, _vp, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), _vp]),
+    "bh_chains_get_rng": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_double)]),
+    "bh_chains_set_rng": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_double]),
+    "bh_chains_draw": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp]),
     "bh_version": (C.c_char_p, []),
     "bh_last_error": (C.c_char_p, []),
     "bh_device_count": (C.c_int, [C.POINTER(C.c_int)]),

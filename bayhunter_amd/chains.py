@@ -1,0 +1,375 @@
+"""Lock-step chain pool: many Markov chains advanced together, one batch of proposals per iteration.
+
+The reference runs `SingleChain.run_chain()` in one process per chain (src/mcmcOptimizer.py:202-283)
+and every `iterate()` (src/SingleChain.py:511-589) evaluates ONE model.  Here all chains of a pool
+make their move at the same time:
+
+    host (libbayhunter_amd, bh_chains_propose)    each chain draws its move from its own
+                                                  RandomState stream, builds the proposal, checks priors
+    GPU  (JointTarget.evaluate_batch)             forward models + likelihood of every valid proposal
+    host (bh_chains_accept)                       u = log(uniform) per chain, accept / store / adapt
+
+The per-chain arithmetic and the order of random draws are the reference's, so chain i of a pool is
+the chain the reference would have produced with the same seed (tests/test_chains.py drives the
+reference's own SingleChain next to it).  The pool is split into groups that alternate between the
+host and the GPU: while one group's proposals are on the device, the other group is being accepted
+and re-proposed on the host cores.
+
+`ChainPool.save()` writes the reference's result files (src/SingleChain.py:608-690:
+`c%03d_p{1,2}{models,likes,misfits,noise,vpvs}.npy` + `<station>_config.pkl`), so its
+`PlotFromStorage` reads a GPU-produced inversion unchanged.
+"""
+import ctypes as C
+import os
+import pickle
+
+import numpy as np
+
+from . import _lib
+
+# src/defaults/defaults.ini of the reference (what utils.load_params returns for it)
+DEFAULT_PRIORS = dict(mantle=None, vpvs=(1.5, 2.1), layers=(1, 20), vs=(1, 5), z=(0, 60), mohoest=None,
+                      rfnoise_corr=(0.35, 0.75), rfnoise_sigma=(1e-5, 0.05), swdnoise_corr=0.,
+                      swdnoise_sigma=(1e-5, 0.1))
+DEFAULT_INITPARAMS = dict(nchains=3, iter_burnin=2048 * 2, iter_main=2048, propdist=(0.025, 0.025, 0.015, 0.005, 0.005),
+                          acceptance=(40, 45), thickmin=0., lvz=None, hvz=None, rcond=None,
+                          station='test', savepath='results/', maxmodels=50000)
+
+
+def _is_number(x):
+    return isinstance(x, (int, float, np.floating, np.integer))
+
+
+class _CallEvaluator(object):
+    """Adapter for a plain function (packed, nlay, noise) -> (logL, misfits)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def buffers(self, rows, Lmax, ntargets):
+        return (np.zeros((rows, 4, Lmax)), np.zeros(rows, dtype=np.int32), np.zeros((rows, 2 * ntargets)),
+                np.zeros(rows, dtype=np.int32))
+
+    def submit(self, group, packed, nlay, noise):
+        return self.fn(packed, nlay, noise)
+
+    def collect(self, ticket):
+        logL, misfits = ticket
+        return np.ascontiguousarray(logL, dtype=np.float64), np.ascontiguousarray(misfits, dtype=np.float64)
+
+
+class GpuEvaluator(object):
+    """Proposals -> (logL, misfits) on the device through JointTarget.evaluate_batch.  Proposals are
+    written by the library straight into pinned host buffers; upload, kernels and the download of
+    8*(ntargets+2) bytes per model are queued on one stream and `collect` waits for its event."""
+
+    def __init__(self, joint, device=None):
+        import torch
+        self.torch = torch
+        self.joint = joint
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pin = {}
+
+    def buffers(self, rows, Lmax, ntargets):
+        torch = self.torch
+        bufs = [torch.zeros((rows, 4, Lmax), dtype=torch.float64).pin_memory(),
+                torch.zeros(rows, dtype=torch.int32).pin_memory(),
+                torch.zeros((rows, 2 * ntargets), dtype=torch.float64).pin_memory(),
+                torch.zeros(rows, dtype=torch.int32).pin_memory()]
+        outs = (torch.zeros(rows, dtype=torch.float64).pin_memory(),
+                torch.zeros((rows, ntargets + 1), dtype=torch.float64).pin_memory())
+        views = tuple(b.numpy() for b in bufs)
+        self._pin[views[0].ctypes.data] = (bufs, outs)
+        return views
+
+    def submit(self, group, packed, nlay, noise):
+        torch = self.torch
+        from .engine import DeviceModels
+        B = packed.shape[0]
+        if B == 0:
+            return None
+        bufs, outs = self._pin[packed.ctypes.data]
+        with torch.cuda.stream(self.stream):
+            dp = bufs[0][:B].to(self.device, non_blocking=True)
+            dn = bufs[1][:B].to(self.device, non_blocking=True)
+            dz = bufs[2][:B].to(self.device, non_blocking=True)
+            logL, misfits = self.joint.evaluate_batch(DeviceModels(dp, dn), noise=dz)
+            outs[0][:B].copy_(logL, non_blocking=True)
+            outs[1][:B].copy_(misfits, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return ev, outs, B
+
+    def collect(self, ticket):
+        if ticket is None:
+            return np.zeros(0), np.zeros((0, self.joint.ntargets + 1))
+        ev, outs, B = ticket
+        ev.synchronize()
+        return outs[0].numpy()[:B], outs[1].numpy()[:B]
+
+
+class _Group(object):
+    """A contiguous range of chains behind one bh_chain_pool handle."""
+
+    def __init__(self, lib, cfg, seeds, arrays, first, last, Lmax, evaluator, ntargets):
+        self.lib, self.first, self.last = lib, first, last
+        n = last - first
+        self.n, self.Lmax = n, Lmax
+        st = _lib.ChainStorage()
+        st.nmodels = arrays['likes'].shape[1]
+        keep = []
+        for name in ('models', 'misfits', 'likes', 'noise', 'vpvs', 'iter'):
+            part = arrays[name][first:last]
+            assert part.flags['C_CONTIGUOUS']
+            keep.append(part)
+            setattr(st, name, part.ctypes.data)
+        self._keep = keep
+        self.seeds = np.ascontiguousarray(seeds[first:last], dtype=np.uint32)
+        self.handle = C.c_void_p()
+        _lib.check(lib.bh_chains_create(C.byref(cfg), n, self.seeds.ctypes.data, C.byref(st), C.byref(self.handle)))
+        self.packed, self.nlay, self.noise, self.chain = evaluator.buffers(n, Lmax, ntargets)
+        self.count = 0
+        self.ticket = None
+
+    def propose(self):
+        cnt = C.c_int(0)
+        _lib.check(self.lib.bh_chains_propose(self.handle, self.Lmax, self.packed.ctypes.data, self.nlay.ctypes.data,
+                                              self.noise.ctypes.data, self.chain.ctypes.data, C.byref(cnt)))
+        self.count = cnt.value
+        return self.count
+
+    def accept(self, logL, misfits):
+        assert logL.shape[0] == self.count and logL.dtype == np.float64 and misfits.dtype == np.float64
+        logL, misfits = np.ascontiguousarray(logL), np.ascontiguousarray(misfits)
+        _lib.check(self.lib.bh_chains_accept(self.handle, logL.ctypes.data, misfits.ctypes.data))
+
+    def done(self):
+        return bool(self.lib.bh_chains_done(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.lib.bh_chains_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class ChainPool(object):
+    """`ChainPool(targets, initparams, modelpriors, random_seed=...)`: the arguments of the
+    reference's MCMC_Optimizer (src/mcmcOptimizer.py:35-75); `targets` is a bayhunter_amd JointTarget.
+
+    nchains      overrides initparams['nchains']
+    seeds        per-chain RandomState seeds; default: drawn like the reference's optimizer does,
+                 `RandomState(random_seed).randint(1000)` per chain (:133-137)
+    evaluator    object with buffers/submit/collect (default GpuEvaluator) or a plain function
+                 (packed[B,4,Lmax], nlay[B], noise[B,2*ntargets]) -> (logL[B], misfits[B,ntargets+1])
+    groups       number of chain groups alternating between host and GPU (default 2 when the pool
+                 has at least 512 chains, else 1)
+    """
+
+    def __init__(self, targets, initparams=None, modelpriors=None, random_seed=None, nchains=None,
+                 seeds=None, evaluator=None, groups=None, nthreads=None):
+        self.lib = _lib.load()
+        self.targets = targets
+        self.priors = dict(DEFAULT_PRIORS)
+        self.priors.update(modelpriors or {})
+        self.initparams = dict(DEFAULT_INITPARAMS)
+        self.initparams.update(initparams or {})
+        if nchains is None and seeds is not None:
+            nchains = len(seeds)
+        if nchains is not None:
+            self.initparams['nchains'] = int(nchains)
+        self.nchains = int(self.initparams['nchains'])
+        self.ntargets = targets.ntargets
+        if self.ntargets > _lib.MAX_TARGETS:
+            raise ValueError("at most %d targets" % _lib.MAX_TARGETS)
+        self.iter_burnin, self.iter_main = int(self.initparams['iter_burnin']), int(self.initparams['iter_main'])
+        self.iterations = self.iter_burnin + self.iter_main
+        self.maxlayers = int(self.priors['layers'][1]) + 1
+        self.Lmax = max(8, self.maxlayers)
+        if seeds is None:
+            rstate = np.random.RandomState(random_seed)
+            seeds = [rstate.randint(1000) for _ in range(self.nchains)]
+        self.seeds = np.asarray(seeds, dtype=np.uint32)
+        if self.seeds.size != self.nchains:
+            raise ValueError("one seed per chain")
+        self.cfg, corrfix, corr = self._config()
+        # SingleChain._init_model_and_currentvalues -> set_target_covariance(corrfix[::2], inoise[::2], rcond):
+        # a fixed correlation is the same number for every chain, a free one selects the exponential law
+        targets.set_target_covariance(corrfix, corr, self.initparams['rcond'])
+        # the reference's shared arrays (src/mcmcOptimizer.py:77-125)
+        self.nmodels = int(self.iterations * np.max(self.initparams['acceptance']) / 100.)
+        if self.nmodels < 1:
+            raise ValueError("iterations * max(acceptance) / 100 leaves no room for accepted models")
+        f32 = np.float32
+        shape = (self.nchains, self.nmodels)
+        self.models = np.full(shape + (self.maxlayers * 2,), np.nan, dtype=f32)
+        self.misfits = np.full(shape + (self.ntargets + 1,), np.nan, dtype=f32)
+        self.likes = np.full(shape, np.nan, dtype=f32)
+        self.noise = np.full(shape + (self.ntargets * 2,), np.nan, dtype=f32)
+        self.vpvs = np.full(shape, np.nan, dtype=f32)
+        self.iter = np.full(shape, np.nan, dtype=np.float64)
+        arrays = dict(models=self.models, misfits=self.misfits, likes=self.likes, noise=self.noise,
+                      vpvs=self.vpvs, iter=self.iter)
+        if evaluator is None:
+            evaluator = GpuEvaluator(targets)
+        elif not hasattr(evaluator, 'submit'):
+            evaluator = _CallEvaluator(evaluator)
+        self.evaluator = evaluator
+        if groups is None:
+            groups = 2 if self.nchains >= 512 else 1
+        groups = max(1, min(int(groups), self.nchains))
+        bounds = [(g * self.nchains) // groups for g in range(groups + 1)]
+        self.groups = [_Group(self.lib, self.cfg, self.seeds, arrays, bounds[g], bounds[g + 1], self.Lmax,
+                              evaluator, self.ntargets) for g in range(groups)]
+        if nthreads is not None:
+            for g in self.groups:
+                _lib.check(self.lib.bh_chains_set_threads(g.handle, int(nthreads)))
+        self.evaluated = 0
+        self._finished = False
+
+    def __del__(self):
+        for g in getattr(self, 'groups', ()):
+            g.close()
+
+    # -- configuration -----------------------------------------------------------------------
+    def _config(self):
+        pr, ip = self.priors, self.initparams
+        c = _lib.ChainConfig()
+        c.ntargets = self.ntargets
+        c.layers_min, c.layers_max = int(pr['layers'][0]), int(pr['layers'][1])
+        c.vs_min, c.vs_max = float(pr['vs'][0]), float(pr['vs'][1])
+        c.z_min, c.z_max = float(pr['z'][0]), float(pr['z'][1])
+        if _is_number(pr['vpvs']):
+            c.vpvs_fixed, c.vpvs_min, c.vpvs_max = 1, float(pr['vpvs']), float(pr['vpvs'])
+        else:
+            c.vpvs_fixed, c.vpvs_min, c.vpvs_max = 0, float(pr['vpvs'][0]), float(pr['vpvs'][1])
+        if pr.get('mantle') is not None:
+            c.has_mantle, c.mantle_vs, c.mantle_vpvs = 1, float(pr['mantle'][0]), float(pr['mantle'][1])
+        if pr.get('mohoest') is not None:
+            c.has_mohoest, c.moho_mean, c.moho_std = 1, float(pr['mohoest'][0]), float(pr['mohoest'][1])
+        c.thickmin = float(ip['thickmin'])
+        if ip.get('lvz') is not None:
+            c.has_lvz, c.lvz = 1, float(ip['lvz'])
+        if ip.get('hvz') is not None:
+            c.has_hvz, c.hvz = 1, float(ip['hvz'])
+        for i, v in enumerate(ip['propdist']):
+            c.propdist[i] = float(v)
+        c.acceptance[0], c.acceptance[1] = float(ip['acceptance'][0]), float(ip['acceptance'][1])
+        c.iter_burnin, c.iter_main = self.iter_burnin, self.iter_main
+        corrfix, corr = [], []
+        for t, target in enumerate(self.targets.targets):
+            for j, name in enumerate(('noise_corr', 'noise_sigma')):
+                prior = pr[target.noiseref + name]
+                k = 2 * t + j
+                if _is_number(prior):
+                    c.noise_fixed[k], c.noise_lo[k], c.noise_hi[k] = 1, float(prior), float(prior)
+                else:
+                    c.noise_fixed[k], c.noise_lo[k], c.noise_hi[k] = 0, float(prior[0]), float(prior[1])
+                if j == 0:
+                    corrfix.append(bool(c.noise_fixed[k]))
+                    corr.append(c.noise_lo[k])
+        return c, corrfix, corr
+
+    # -- running -----------------------------------------------------------------------------
+    def _launch(self, g):
+        n = g.propose()
+        self.evaluated += n
+        g.ticket = self.evaluator.submit(g, g.packed[:n], g.nlay[:n], g.noise[:n])
+
+    def _land(self, g):
+        logL, misfits = self.evaluator.collect(g.ticket)
+        g.ticket = None
+        g.accept(logL, misfits)
+
+    def run(self, progress=None):
+        """Initial models, then iter_burnin + iter_main iterations of every chain."""
+        if self._finished:
+            return self
+        for g in self.groups:
+            self._launch(g)                       # initial models of every group in flight
+        live = list(self.groups)
+        step = 0
+        while live:
+            for g in list(live):
+                self._land(g)
+                if g.done():
+                    live.remove(g)
+                else:
+                    self._launch(g)
+            step += 1
+            if progress is not None and step % progress[0] == 0:
+                progress[1](self)
+        self._finished = True
+        return self
+
+    @property
+    def iteration(self):
+        return min(self.lib.bh_chains_iteration(g.handle) for g in self.groups)
+
+    # -- results -----------------------------------------------------------------------------
+    def counters(self):
+        """naccepted[nchains], propdist / accepted / proposed [nchains, 5]."""
+        n = np.zeros(self.nchains, dtype=np.int64)
+        pd, acc, pro = (np.zeros((self.nchains, 5)) for _ in range(3))
+        for g in self.groups:
+            sl = slice(g.first, g.last)
+            parts = [np.ascontiguousarray(a[sl]) for a in (n, pd, acc, pro)]
+            _lib.check(self.lib.bh_chains_counters(g.handle, *[p.ctypes.data for p in parts]))
+            n[sl], pd[sl], acc[sl], pro[sl] = parts
+        return n, pd, acc, pro
+
+    def chain(self, i):
+        """What a finished reference chain holds in chainmodels/chainlikes/... (rows up to n)."""
+        n = int(self.counters()[0][i])
+        return dict(n=n, models=self.models[i, :n], likes=self.likes[i, :n], misfits=self.misfits[i, :n],
+                    noise=self.noise[i, :n], vpvs=self.vpvs[i, :n], iter=self.iter[i, :n])
+
+    def weighted(self, i):
+        """Residence-time weighting of one chain, SingleChain.run_chain's tail (:608-652) and
+        ModelMatrix.get_weightedvalues (src/Models.py:228-274): an accepted model is repeated once
+        per iteration it stayed current.  -> {1: (models, likes, misfits, noise, vpvs) | None, 2: ...}"""
+        ch = self.chain(i)
+        out = {}
+        for phase, sel, final in ((1, ch['iter'] < 0, 0), (2, ch['iter'] >= 0, self.iter_main)):
+            if not np.any(sel):
+                out[phase] = None
+                continue
+            w = np.diff(np.concatenate((ch['iter'][sel], [final]))).astype(int)
+            rep = lambda a, wide: np.repeat(a[sel].astype(np.float64) if wide else a[sel], w, axis=0)
+            # the reference fills float64 matrices for models/misfits/noise and repeats the float32
+            # vectors of likes and vpvs
+            out[phase] = (rep(ch['models'], True), rep(ch['likes'], False), rep(ch['misfits'], True),
+                          rep(ch['noise'], True), rep(ch['vpvs'], False))
+        return out
+
+    def save(self, savepath=None, chainidx_offset=0):
+        """Write <savepath>/data/c%03d_p{1,2}{models,likes,misfits,noise,vpvs}.npy like
+        SingleChain.save_finalmodels (:654-690), thinned to initparams['maxmodels'] main-phase
+        models per chain, and <station>_config.pkl like utils.save_config (src/utils.py:127-153).
+        (The reference's PlotFromStorage globs `c???_...`: it sees chain numbers up to 999.)"""
+        savepath = savepath or self.initparams['savepath']
+        data = os.path.join(savepath, 'data')
+        os.makedirs(data, exist_ok=True)
+        names = ('models', 'likes', 'misfits', 'noise', 'vpvs')
+        written = 0
+        for i in range(self.nchains):
+            w = self.weighted(i)
+            thinning = 1
+            if w[2] is not None:
+                thinning = int(np.ceil(float(w[2][1].size) / float(self.initparams['maxmodels'])))
+            for phase in (1, 2):
+                if w[phase] is None:
+                    continue
+                for name, arr in zip(names, w[phase]):
+                    np.save(os.path.join(data, 'c%.3d_p%d%s' % (i + chainidx_offset, phase, name)), arr[::thinning])
+                    written += 1
+        for target in self.targets.targets:
+            target.get_covariance = None
+        cfg = dict(targets=self.targets.targets, targetrefs=[t.ref for t in self.targets.targets],
+                   priors=self.priors, initparams=self.initparams)
+        with open(os.path.join(data, '%s_config.pkl' % self.initparams['station']), 'wb') as f:
+            pickle.dump(cfg, f)
+        corrfix = [bool(self.cfg.noise_fixed[2 * t]) for t in range(self.ntargets)]
+        corr = [self.cfg.noise_lo[2 * t] for t in range(self.ntargets)]
+        self.targets.set_target_covariance(corrfix, corr, self.initparams['rcond'])
+        return written

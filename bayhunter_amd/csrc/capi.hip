@@ -27,6 +27,10 @@ int fail_arg(const char *what)
     g_err = what;
     return BH_ERR_ARG;
 }
+}  // namespace
+// shared with chains.cpp (host-only translation unit)
+namespace bh { int fail_arg_(const char *what) { g_err = what; return BH_ERR_ARG; } }
+namespace {
 #define BH_HIP(call)                                          \
     do {                                                      \
         hipError_t e_ = (call);                               \

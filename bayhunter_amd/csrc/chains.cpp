@@ -1,0 +1,614 @@
+// Lock-step chain pool: the host side of the sampler for MANY chains advanced together
+// (C ABI: bh_chains_*, include/bayhunter_amd.h).  No device work in here.
+//
+// What one chain does per iteration follows src/SingleChain.py of the reference:
+//   iterate()                       :511-589   choose a move, build the proposal, check the priors,
+//                                              [forward + likelihood], u = log(uniform), accept/store
+//   _model_vschange/_zvnoi_move     :286-298   one nucleus, Gaussian step
+//   _model_layerbirth/_layerdeath   :246-284   add / remove a nucleus, remember (delta vs)^2
+//   _sort_modelproposal             :315-328   nuclei ordered by depth
+//   _validmodel/_validnoise/_validvpvs :330-434
+//   get_acceptance_probability      :463-497   likelihood ratio (+ the birth/death terms of Bodin 2012)
+//   adjust_propdist                 :439-461   every 1000 iterations, +-5 % towards the window
+//   draw_initvpvs/initmodel/initnoiseparams :94-157
+//   append_currentmodel             :508-517   float32 rows + the iteration of acceptance
+// and Model.get_vp_vs_h / get_vp (src/Models.py:26-52) for nuclei -> layers.
+//
+// The random numbers are numpy.random.RandomState's: MT19937 seeded with init_genrand(seed), doubles
+// from two outputs (a>>5, b>>6), the polar Box-Muller `legacy_gauss` with its cached second value,
+// and `randint` by masked rejection on 32-bit outputs.  The order of draws is the reference's, so a
+// chain here and a reference chain with the same seed see the same numbers.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/bayhunter_amd.h"
+
+namespace bh { int fail_arg_(const char *what); }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// numpy.random.RandomState
+struct Rng {
+    uint32_t key[624];
+    int pos;
+    int has_gauss;
+    double gauss;
+
+    void seed(uint32_t s)
+    {
+        for (int i = 0; i < 624; i++) {
+            key[i] = s;
+            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
+        }
+        pos = 624;
+        has_gauss = 0;
+        gauss = 0.0;
+    }
+    void refill()
+    {
+        const uint32_t A = 0x9908b0dfu, UP = 0x80000000u, LO = 0x7fffffffu;
+        int i;
+        uint32_t y;
+        for (i = 0; i < 624 - 397; i++) {
+            y = (key[i] & UP) | (key[i + 1] & LO);
+            key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        for (; i < 623; i++) {
+            y = (key[i] & UP) | (key[i + 1] & LO);
+            key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        }
+        y = (key[623] & UP) | (key[0] & LO);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        pos = 0;
+    }
+    uint32_t next32()
+    {
+        if (pos >= 624) refill();
+        uint32_t y = key[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    double next_double()
+    {
+        int32_t a = (int32_t)(next32() >> 5), b = (int32_t)(next32() >> 6);
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    double uniform(double lo, double hi)
+    {
+        double width = hi - lo;
+        return lo + width * next_double();
+    }
+    double std_gauss()
+    {
+        if (has_gauss) {
+            double g = gauss;
+            has_gauss = 0;
+            gauss = 0.0;
+            return g;
+        }
+        double x1, x2, r2;
+        do {
+            x1 = 2.0 * next_double() - 1.0;
+            x2 = 2.0 * next_double() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        double f = std::sqrt(-2.0 * std::log(r2) / r2);
+        gauss = f * x1;
+        has_gauss = 1;
+        return f * x2;
+    }
+    double normal(double loc, double scale) { return loc + scale * std_gauss(); }
+    long randint(long lo, long hi)      // [lo, hi)
+    {
+        uint64_t span = (uint64_t)(hi - 1 - lo);
+        if (span == 0) return lo;
+        uint64_t mask = span;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;
+        mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+        if (span <= 0xffffffffull) {
+            if (span == 0xffffffffull) return lo + (long)next32();
+            uint32_t v;
+            do { v = next32() & (uint32_t)mask; } while (v > span);
+            return lo + (long)v;
+        }
+        uint64_t v;
+        do {
+            uint64_t hi32 = next32(), lo32 = next32();
+            v = ((hi32 << 32) | lo32) & mask;
+        } while (v > span);
+        return lo + (long)v;
+    }
+};
+
+enum Move { VSMOD = 0, ZVMOD = 1, BIRTH = 2, DEATH = 3, NOISE = 4, VPVS = 5 };
+const int PAR_OF_MOVE[6] = {0, 1, 2, 2, 3, 4};          // PAR_MAP, SingleChain.py:22-23
+const int MAXN = 2 * BH_MAX_TARGETS;
+
+struct Chain {
+    Rng rng;
+    int n;                                   // nuclei of the current model
+    std::vector<double> vs, z;
+    double noise[MAXN], vpvs, like, misfits[BH_MAX_TARGETS + 1];
+    double propdist[5], accepted[5], proposed[5];
+    long nstored, lastmoditer;
+    // proposal of the running iteration
+    int pn, move, valid, slot;
+    std::vector<double> pvs, pz;
+    double pnoise[MAXN], pvpvs, dvs2;
+};
+
+}  // namespace
+
+struct bh_chain_pool {
+    bh_chain_config cfg;
+    bh_chain_storage st;
+    int nchains, maxl, nthreads;
+    long iiter, iterations;
+    int stage;                               // 0: initial models next, 1: their results awaited,
+                                             // 2: proposals next, 3: their results awaited
+    int count, failed;
+    std::vector<int> noiseinds;
+    std::vector<Chain> chains;
+};
+
+namespace {
+
+template <class F>
+void for_chains(bh_chain_pool *p, F f)
+{
+    int nt = std::max(1, std::min(p->nthreads, p->nchains / 256));
+    if (nt == 1) {
+        for (int i = 0; i < p->nchains; i++) f(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    int per = (p->nchains + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) {
+        int lo = t * per, hi = std::min(p->nchains, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([=]() { for (int i = lo; i < hi; i++) f(i); });
+    }
+    for (auto &t : th) t.join();
+}
+
+// Model.get_vp_vs_h: interfaces midway between neighbouring nuclei, half space h = 0
+void layers_of(const bh_chain_config &c, int n, const double *vs, const double *z, double vpvs,
+               double *h, double *vp)
+{
+    double prev = 0.0;
+    for (int i = 0; i + 1 < n; i++) {
+        double mid = (z[i] + z[i + 1]) / 2.;
+        h[i] = mid - prev;
+        prev = mid;
+    }
+    h[n - 1] = 0.0;
+    int deep = n;
+    if (c.has_mantle)
+        for (int i = 0; i < n; i++)
+            if (vs[i] >= c.mantle_vs) { deep = i; break; }
+    for (int i = 0; i < n; i++) vp[i] = vs[i] * (i < deep ? vpvs : c.mantle_vpvs);
+}
+
+bool valid_model(const bh_chain_config &c, int n, const double *vs, const double *z)
+{
+    int layers = n - 1;
+    if (!(layers >= c.layers_min && layers <= c.layers_max)) return false;
+    double prev = 0.0, depth = 0.0;
+    for (int i = 0; i < n; i++) {
+        double h = 0.0;
+        if (i + 1 < n) {
+            double mid = (z[i] + z[i + 1]) / 2.;
+            h = mid - prev;
+            prev = mid;
+            if (h < c.thickmin) return false;
+        }
+        depth = (i == 0) ? h : depth + h;            // np.cumsum
+        if (depth < c.z_min || depth > c.z_max) return false;
+    }
+    for (int i = 0; i < n; i++)
+        if (vs[i] < c.vs_min || vs[i] > c.vs_max) return false;
+    if (c.has_lvz)
+        for (int i = 0; i + 1 < n; i++)
+            if (!(vs[i + 1] - vs[i] * (1 - c.lvz) > 0)) return false;
+    if (c.has_hvz)
+        for (int i = 0; i + 1 < n; i++)
+            if (!(vs[i] * (1 + c.hvz) - vs[i + 1] > 0)) return false;
+    return true;
+}
+
+// the checks above return at the first violated rule; the reference tests them in the order layer
+// count, thickness, vs, depth, lvz, hvz -- the verdict is the same, and nothing random depends on
+// which rule fired.
+
+void sort_by_depth(int n, double *vs, double *z)
+{
+    bool ordered = true;
+    for (int i = 0; i + 1 < n; i++)
+        if (!(z[i + 1] - z[i] > 0)) { ordered = false; break; }
+    if (ordered) return;
+    int idx[BH_MAX_LAYERS + 2];
+    double tv[BH_MAX_LAYERS + 2], tz[BH_MAX_LAYERS + 2];
+    for (int i = 0; i < n; i++) idx[i] = i;
+    std::stable_sort(idx, idx + n, [&](int a, int b) { return z[a] < z[b]; });
+    for (int i = 0; i < n; i++) { tv[i] = vs[idx[i]]; tz[i] = z[idx[i]]; }
+    std::memcpy(vs, tv, n * sizeof(double));
+    std::memcpy(z, tz, n * sizeof(double));
+}
+
+int nearest(int n, const double *z, double z0)
+{
+    int best = 0;
+    double d = std::fabs(z[0] - z0);
+    for (int i = 1; i < n; i++) {
+        double di = std::fabs(z[i] - z0);
+        if (di < d) { d = di; best = i; }
+    }
+    return best;
+}
+
+void initial_model(bh_chain_pool *p, Chain &c)
+{
+    const bh_chain_config &g = p->cfg;
+    // draw_initvpvs
+    c.pvpvs = g.vpvs_fixed ? g.vpvs_min : c.rng.uniform(g.vpvs_min, g.vpvs_max);
+    // draw_initmodel: the minimum number of layers, redrawn until the priors hold
+    int n = g.layers_min + 1;
+    for (;;) {
+        for (int i = 0; i < n; i++) c.pvs[i] = c.rng.uniform(g.vs_min, g.vs_max);
+        std::sort(c.pvs.begin(), c.pvs.begin() + n);
+        if (g.has_mohoest && n > 1) {
+            double moho = c.rng.normal(g.moho_mean, g.moho_std);
+            double half = c.rng.uniform(1, std::min(5.0, moho));
+            c.pz[0] = moho - half;
+            c.pz[1] = moho + half;
+            for (int i = 2; i < n; i++) c.pz[i] = c.rng.uniform(g.z_min, g.z_max);
+        } else {
+            for (int i = 0; i < n; i++) c.pz[i] = c.rng.uniform(g.z_min, g.z_max);
+        }
+        std::sort(c.pz.begin(), c.pz.begin() + n);
+        if (valid_model(g, n, c.pvs.data(), c.pz.data())) break;
+    }
+    c.pn = n;
+    // draw_initnoiseparams
+    for (int i = 0; i < 2 * g.ntargets; i++)
+        c.pnoise[i] = g.noise_fixed[i] ? g.noise_lo[i] : c.rng.uniform(g.noise_lo[i], g.noise_hi[i]);
+    c.valid = 1;
+    c.move = -1;
+}
+
+void propose(bh_chain_pool *p, Chain &c)
+{
+    const bh_chain_config &g = p->cfg;
+    const int nnoise = p->noiseinds.empty() ? 0 : 1, nvpvs = g.vpvs_fixed ? 0 : 1;
+    // only vs and depth moves (and the hyper-parameters) during the first 1 % of the iterations
+    bool early = (double)p->iiter < (double)(-g.iter_burnin) + (double)p->iterations * 0.01;
+    int k = (int)c.rng.randint(0, (early ? 2 : 4) + nnoise + nvpvs);
+    int nmodel = early ? 2 : 4;
+    int move = k < nmodel ? k : (k - nmodel < nnoise ? NOISE : VPVS);
+    c.move = move;
+    int n = c.n;
+    std::memcpy(c.pvs.data(), c.vs.data(), n * sizeof(double));
+    std::memcpy(c.pz.data(), c.z.data(), n * sizeof(double));
+    std::memcpy(c.pnoise, c.noise, sizeof(c.noise));
+    c.pvpvs = c.vpvs;
+    c.pn = n;
+    c.valid = 1;
+    switch (move) {
+    case VSMOD: {
+        long i = c.rng.randint(0, n);
+        double step = c.rng.normal(0, c.propdist[0]);
+        c.pvs[i] = c.pvs[i] + step;
+        break;
+    }
+    case ZVMOD: {
+        long i = c.rng.randint(n, 2 * n) - n;
+        double step = c.rng.normal(0, c.propdist[1]);
+        c.pz[i] = c.pz[i] + step;
+        break;
+    }
+    case BIRTH: {
+        double zb = c.rng.uniform(g.z_min, g.z_max);
+        double before = c.vs[nearest(n, c.z.data(), zb)];
+        double vb = before + c.rng.normal(0, c.propdist[2]);
+        c.pz[n] = zb;
+        c.pvs[n] = vb;
+        c.pn = n + 1;
+        double d = vb - before;
+        c.dvs2 = d * d;
+        break;
+    }
+    case DEATH: {
+        long gone = c.rng.randint(0, n);
+        double zg = c.z[gone], vg = c.vs[gone];
+        for (int i = (int)gone; i + 1 < n; i++) { c.pvs[i] = c.pvs[i + 1]; c.pz[i] = c.pz[i + 1]; }
+        c.pn = n - 1;
+        if (c.pn < 1) { c.valid = 0; break; }     // the reference cannot remove the last nucleus
+        double d = c.pvs[nearest(c.pn, c.pz.data(), zg)] - vg;
+        c.dvs2 = d * d;
+        break;
+    }
+    case NOISE: {
+        int i = p->noiseinds[c.rng.randint(0, (long)p->noiseinds.size())];
+        double step = c.rng.normal(0, c.propdist[3]);
+        c.pnoise[i] = c.pnoise[i] + step;
+        for (int j : p->noiseinds)
+            if (c.pnoise[j] < g.noise_lo[j] || c.pnoise[j] > g.noise_hi[j]) c.valid = 0;
+        return;
+    }
+    case VPVS: {
+        double step = c.rng.normal(0, c.propdist[4]);
+        c.pvpvs = c.pvpvs + step;
+        if (c.pvpvs < g.vpvs_min || c.pvpvs > g.vpvs_max) c.valid = 0;
+        return;
+    }
+    }
+    if (!c.valid) return;
+    sort_by_depth(c.pn, c.pvs.data(), c.pz.data());
+    c.valid = valid_model(g, c.pn, c.pvs.data(), c.pz.data()) ? 1 : 0;
+}
+
+bool store(bh_chain_pool *p, int ci, Chain &c)
+{
+    const bh_chain_storage &s = p->st;
+    if (c.nstored >= s.nmodels) return false;
+    const int T = p->cfg.ntargets, W = 2 * p->maxl;
+    long row = (long)ci * s.nmodels + c.nstored;
+    float *m = s.models + row * W;
+    for (int i = 0; i < c.n; i++) { m[i] = (float)c.vs[i]; m[c.n + i] = (float)c.z[i]; }
+    for (int i = 0; i <= T; i++) s.misfits[row * (T + 1) + i] = (float)c.misfits[i];
+    s.likes[row] = (float)c.like;
+    for (int i = 0; i < 2 * T; i++) s.noise[row * 2 * T + i] = (float)c.noise[i];
+    s.vpvs[row] = (float)c.vpvs;
+    s.iter[row] = (double)p->iiter;
+    c.nstored++;
+    return true;
+}
+
+void take_proposal(bh_chain_pool *p, Chain &c, const double *logL, const double *misfits)
+{
+    const int T = p->cfg.ntargets;
+    c.like = logL[c.slot];
+    std::memcpy(c.misfits, misfits + (long)c.slot * (T + 1), (T + 1) * sizeof(double));
+    c.n = c.pn;
+    std::memcpy(c.vs.data(), c.pvs.data(), c.pn * sizeof(double));
+    std::memcpy(c.z.data(), c.pz.data(), c.pn * sizeof(double));
+    std::memcpy(c.noise, c.pnoise, sizeof(c.noise));
+    c.vpvs = c.pvpvs;
+    c.lastmoditer = p->iiter;
+}
+
+void adjust_propdist(const bh_chain_config &g, Chain &c)
+{
+    for (int i = 0; i < 5; i++)
+        if (c.proposed[i] == 0) return;
+    for (int i = 0; i < 5; i++) {
+        double rate = c.accepted[i] / c.proposed[i] * 100;
+        if (rate < g.acceptance[0]) {
+            double w = c.propdist[i] * 0.95;
+            c.propdist[i] = w < 0.001 ? 0.001 : w;
+        } else if (rate > g.acceptance[1]) {
+            c.propdist[i] = c.propdist[i] * 1.05;
+        }
+    }
+}
+
+bool decide(bh_chain_pool *p, int ci, Chain &c, const double *logL, const double *misfits)
+{
+    const bh_chain_config &g = p->cfg;
+    bool ok = true;
+    if (!c.valid) return true;                      // iterate() returned before anything else
+    int par = PAR_OF_MOVE[c.move];
+    c.proposed[par] += 1;
+    double u = std::log(c.rng.uniform(0, 1));
+    double ratio = logL[c.slot] - c.like, alpha = ratio;
+    if (c.move == BIRTH || c.move == DEATH) {
+        double theta = c.propdist[2], dv = g.vs_max - g.vs_min;
+        double B = c.dvs2 / (2. * (theta * theta));
+        if (c.move == BIRTH) {
+            double A = (theta * std::sqrt(2 * M_PI)) / dv;
+            alpha = std::log(A) + B + ratio;
+        } else {
+            double A = dv / (theta * std::sqrt(2 * M_PI));
+            alpha = std::log(A) - B + ratio;
+        }
+    }
+    if (u < alpha) {
+        take_proposal(p, c, logL, misfits);
+        ok = store(p, ci, c);
+        c.accepted[par] += 1;
+    }
+    if (((p->iiter % 1000) + 1000) % 1000 == 0) adjust_propdist(g, c);
+    return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bh_chains_create(const bh_chain_config *cfg, int nchains, const unsigned *seeds,
+                     const bh_chain_storage *st, bh_chain_pool **out)
+{
+    if (!cfg || !seeds || !st || !out || nchains < 1) return bh::fail_arg_("bh_chains_create: NULL argument or no chains");
+    if (cfg->ntargets < 1 || cfg->ntargets > BH_MAX_TARGETS) return bh::fail_arg_("bh_chains_create: ntargets out of range");
+    if (cfg->layers_min < 0 || cfg->layers_max < cfg->layers_min || cfg->layers_max + 1 > BH_MAX_LAYERS)
+        return bh::fail_arg_("bh_chains_create: layer prior out of range");
+    if (!st->models || !st->misfits || !st->likes || !st->noise || !st->vpvs || !st->iter || st->nmodels < 1)
+        return bh::fail_arg_("bh_chains_create: storage arrays missing");
+    if (cfg->iter_burnin < 0 || cfg->iter_main < 0) return bh::fail_arg_("bh_chains_create: negative iteration count");
+    bh_chain_pool *p = new (std::nothrow) bh_chain_pool();
+    if (!p) return bh::fail_arg_("bh_chains_create: out of memory");
+    p->cfg = *cfg;
+    p->st = *st;
+    p->nchains = nchains;
+    p->maxl = cfg->layers_max + 1;
+    p->nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    p->iterations = cfg->iter_burnin + cfg->iter_main;
+    p->iiter = -cfg->iter_burnin;
+    p->stage = 0;
+    p->count = 0;
+    p->failed = 0;
+    for (int i = 0; i < 2 * cfg->ntargets; i++)
+        if (!cfg->noise_fixed[i]) p->noiseinds.push_back(i);
+    p->chains.resize(nchains);
+    for (int i = 0; i < nchains; i++) {
+        Chain &c = p->chains[i];
+        c.rng.seed(seeds[i]);
+        c.n = 0;
+        c.vs.assign(p->maxl + 2, 0.0); c.z.assign(p->maxl + 2, 0.0);
+        c.pvs.assign(p->maxl + 2, 0.0); c.pz.assign(p->maxl + 2, 0.0);
+        std::memset(c.noise, 0, sizeof(c.noise)); std::memset(c.pnoise, 0, sizeof(c.pnoise));
+        std::memset(c.misfits, 0, sizeof(c.misfits));
+        c.vpvs = c.pvpvs = 0.0; c.like = 0.0; c.dvs2 = 0.0;
+        for (int k = 0; k < 5; k++) { c.propdist[k] = cfg->propdist[k]; c.accepted[k] = c.proposed[k] = 0.0; }
+        c.nstored = 0; c.lastmoditer = p->iiter;
+        c.pn = 0; c.move = -1; c.valid = 0; c.slot = -1;
+    }
+    *out = p;
+    return BH_OK;
+}
+
+void bh_chains_destroy(bh_chain_pool *p) { delete p; }
+
+int bh_chains_set_threads(bh_chain_pool *p, int n)
+{
+    if (!p || n < 1) return bh::fail_arg_("bh_chains_set_threads: bad argument");
+    p->nthreads = n;
+    return BH_OK;
+}
+
+int bh_chains_done(const bh_chain_pool *p) { return (p && p->stage >= 2 && p->iiter >= p->cfg.iter_main) ? 1 : 0; }
+long bh_chains_iteration(const bh_chain_pool *p) { return p ? p->iiter : 0; }
+
+int bh_chains_propose(bh_chain_pool *p, int Lmax, double *packed, int *nlay, double *noise,
+                      int *chain, int *count)
+{
+    if (!p || !packed || !nlay || !noise || !chain || !count) return bh::fail_arg_("bh_chains_propose: NULL argument");
+    if (p->failed) return bh::fail_arg_("bh_chains_propose: the pool stopped after an error");
+    if (p->stage != 0 && p->stage != 2) return bh::fail_arg_("bh_chains_propose: results of the last proposals are still due");
+    if (Lmax < p->maxl) return bh::fail_arg_("bh_chains_propose: Lmax smaller than layers_max + 1");
+    if (p->stage == 2 && p->iiter >= p->cfg.iter_main) { *count = 0; return BH_OK; }
+    const bool init = p->stage == 0;
+    for_chains(p, [=](int i) { init ? initial_model(p, p->chains[i]) : propose(p, p->chains[i]); });
+    int k = 0;
+    for (int i = 0; i < p->nchains; i++) {
+        Chain &c = p->chains[i];
+        c.slot = c.valid ? k : -1;
+        if (c.valid) chain[k++] = i;
+    }
+    const int T2 = 2 * p->cfg.ntargets;
+    for_chains(p, [=](int i) {
+        Chain &c = p->chains[i];
+        if (!c.valid) return;
+        double *row = packed + (long)c.slot * 4 * Lmax;
+        std::memset(row, 0, 4 * Lmax * sizeof(double));
+        double *h = row, *vp = row + Lmax, *vs = row + 2 * Lmax, *rho = row + 3 * Lmax;
+        layers_of(p->cfg, c.pn, c.pvs.data(), c.pz.data(), c.pvpvs, h, vp);
+        for (int l = 0; l < c.pn; l++) { vs[l] = c.pvs[l]; rho[l] = vp[l] * 0.32 + 0.77; }
+        nlay[c.slot] = c.pn;
+        std::memcpy(noise + (long)c.slot * T2, c.pnoise, T2 * sizeof(double));
+    });
+    p->count = k;
+    *count = k;
+    p->stage += 1;
+    return BH_OK;
+}
+
+int bh_chains_accept(bh_chain_pool *p, const double *logL, const double *misfits)
+{
+    if (!p || ((!logL || !misfits) && p->count > 0)) return bh::fail_arg_("bh_chains_accept: NULL argument");
+    if (p->stage != 1 && p->stage != 3) return bh::fail_arg_("bh_chains_accept: no proposals outstanding");
+    std::vector<char> bad(p->nchains, 0);
+    char *badp = bad.data();
+    if (p->stage == 1) {
+        for_chains(p, [=](int i) {
+            Chain &c = p->chains[i];
+            take_proposal(p, c, logL, misfits);
+            if (!store(p, i, c)) badp[i] = 1;
+        });
+        p->stage = 2;
+    } else {
+        for_chains(p, [=](int i) { if (!decide(p, i, p->chains[i], logL, misfits)) badp[i] = 1; });
+        p->iiter += 1;
+        p->stage = 2;
+    }
+    for (int i = 0; i < p->nchains; i++)
+        if (bad[i]) {
+            p->failed = 1;
+            return bh::fail_arg_("bh_chains_accept: a chain accepted more models than its storage holds "
+                                 "(nmodels = iterations * max(acceptance) / 100, like the reference's arrays)");
+        }
+    return BH_OK;
+}
+
+int bh_chains_counters(const bh_chain_pool *p, long *naccepted, double *propdist, double *accepted,
+                       double *proposed)
+{
+    if (!p) return bh::fail_arg_("bh_chains_counters: NULL pool");
+    for (int i = 0; i < p->nchains; i++) {
+        const Chain &c = p->chains[i];
+        if (naccepted) naccepted[i] = c.nstored;
+        for (int k = 0; k < 5; k++) {
+            if (propdist) propdist[i * 5 + k] = c.propdist[k];
+            if (accepted) accepted[i * 5 + k] = c.accepted[k];
+            if (proposed) proposed[i * 5 + k] = c.proposed[k];
+        }
+    }
+    return BH_OK;
+}
+
+int bh_chains_current(const bh_chain_pool *p, int ci, int *nnuclei, double *model, double *noise,
+                      double *vpvs, double *like, double *misfits)
+{
+    if (!p || ci < 0 || ci >= p->nchains) return bh::fail_arg_("bh_chains_current: bad chain index");
+    const Chain &c = p->chains[ci];
+    if (nnuclei) *nnuclei = c.n;
+    if (model)
+        for (int i = 0; i < c.n; i++) { model[i] = c.vs[i]; model[c.n + i] = c.z[i]; }
+    if (noise) std::memcpy(noise, c.noise, 2 * p->cfg.ntargets * sizeof(double));
+    if (vpvs) *vpvs = c.vpvs;
+    if (like) *like = c.like;
+    if (misfits) std::memcpy(misfits, c.misfits, (p->cfg.ntargets + 1) * sizeof(double));
+    return BH_OK;
+}
+
+int bh_chains_get_rng(const bh_chain_pool *p, int ci, unsigned *key, int *pos, int *has_gauss, double *gauss)
+{
+    if (!p || ci < 0 || ci >= p->nchains || !key || !pos || !has_gauss || !gauss)
+        return bh::fail_arg_("bh_chains_get_rng: bad argument");
+    const Rng &r = p->chains[ci].rng;
+    std::memcpy(key, r.key, sizeof(r.key));
+    *pos = r.pos; *has_gauss = r.has_gauss; *gauss = r.gauss;
+    return BH_OK;
+}
+
+int bh_chains_set_rng(bh_chain_pool *p, int ci, const unsigned *key, int pos, int has_gauss, double gauss)
+{
+    if (!p || ci < 0 || ci >= p->nchains || !key || pos < 0 || pos > 624)
+        return bh::fail_arg_("bh_chains_set_rng: bad argument");
+    Rng &r = p->chains[ci].rng;
+    std::memcpy(r.key, key, sizeof(r.key));
+    r.pos = pos; r.has_gauss = has_gauss ? 1 : 0; r.gauss = gauss;
+    return BH_OK;
+}
+
+int bh_chains_draw(bh_chain_pool *p, int ci, int kind, double a, double b, int n, double *out)
+{
+    if (!p || ci < 0 || ci >= p->nchains || !out || n < 0 || kind < 0 || kind > 2)
+        return bh::fail_arg_("bh_chains_draw: bad argument");
+    Rng &r = p->chains[ci].rng;
+    for (int i = 0; i < n; i++)
+        out[i] = kind == 0 ? r.uniform(a, b) : kind == 1 ? r.normal(a, b) : (double)r.randint((long)a, (long)b);
+    return BH_OK;
+}
+
+}  // extern "C"

@@ -33,6 +33,12 @@ class _Plugin(object):
         self.modelparams.update(mparams)
         self._engine = None          # parameters are baked into the engine's launch descriptors
 
+    def __getstate__(self):
+        # targets are pickled into <station>_config.pkl (src/utils.py:127-153); device handles stay out
+        state = dict(self.__dict__)
+        state['_engine'] = None
+        return state
+
 
 class SurfDisp(_Plugin):
     """Dispersion curves (Rayleigh/Love, phase/group) for layered models.

@@ -188,6 +188,11 @@ class JointTarget(object):
         self._batch = None
         self.use_mfma = True     # dense Gaussian covariance product on the FP64 matrix cores
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_batch'] = None       # device tensors and launch descriptors are rebuilt on demand
+        return state
+
     def get_misfits(self):
         misfits = [target.valuation.misfit for target in self.targets]
         return np.concatenate((misfits, [np.sum(misfits)]))

@@ -179,6 +179,91 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
  * [-max_exp, max_exp] on the device both ways and counts bitwise differences (expected: 0). */
 int bh_selftest_division(long n, unsigned seed, int max_exp, long *mismatches);
 
+/* ---- lock-step chain pool (host side of the sampler) ------------------------------------ */
+/* Replaces the per-process loop `while iiter < iter_phase2: SingleChain.iterate()`
+ * (src/SingleChain.py:511-589,591-606) for MANY chains advanced together, so that every iteration
+ * hands one batch of proposals to bh_swd_batch / bh_rf_batch / bh_likelihood_batch.  Host code, no
+ * device work: each chain owns a numpy-compatible MT19937 stream (RandomState(seed) with the legacy
+ * uniform / normal / randint algorithms) and replays draw_initvpvs / draw_initmodel /
+ * draw_initnoiseparams (:94-157), the five moves (:246-300,:405-428), _validmodel /_validnoise /
+ * _validvpvs (:317-403,:413-434), get_acceptance_probability (:463-497), adjust_propdist (:439-461)
+ * and append_currentmodel (:508-517) move for move: with the same seed and the same forward values a
+ * chain accepts exactly the models the reference chain accepts.
+ *
+ *   bh_chains_create -> { bh_chains_propose -> [forward + likelihood of `count` models]
+ *                         -> bh_chains_accept } until bh_chains_done
+ *
+ * The first propose/accept pair is the initial model of every chain (_init_model_and_currentvalues,
+ * :71-92: accepted unconditionally); each later pair is one iterate() of every chain. */
+typedef struct bh_chain_pool bh_chain_pool;
+
+typedef struct bh_chain_config {
+    int    ntargets;
+    int    layers_min, layers_max;        /* priors['layers'] (half space not counted)          */
+    double vs_min, vs_max;                /* priors['vs']                                         */
+    double z_min, z_max;                  /* priors['z']                                          */
+    int    vpvs_fixed;                    /* priors['vpvs'] is a float: vpvs_min holds it         */
+    double vpvs_min, vpvs_max;
+    int    has_mantle;                    /* priors['mantle'] = (vs threshold, mantle vp/vs)      */
+    double mantle_vs, mantle_vpvs;
+    int    has_mohoest;                   /* priors['mohoest'] = (mean, std)                      */
+    double moho_mean, moho_std;
+    double thickmin;                      /* initparams['thickmin']                               */
+    int    has_lvz, has_hvz;              /* initparams['lvz'], ['hvz'] (None -> 0)               */
+    double lvz, hvz;
+    double propdist[5];                   /* vs, z, birth/death, noise, vpvs                      */
+    double acceptance[2];                 /* target acceptance window in percent                  */
+    long   iter_burnin, iter_main;
+    int    noise_fixed[2 * BH_MAX_TARGETS]; /* per target (corr, sigma): prior is a number        */
+    double noise_lo[2 * BH_MAX_TARGETS];  /* the number, or the lower bound                       */
+    double noise_hi[2 * BH_MAX_TARGETS];
+} bh_chain_config;
+
+/* Caller-owned sample storage, the layout of the reference's shared arrays
+ * (src/mcmcOptimizer.py:77-125): float32, NaN-filled by the caller, nmodels rows per chain. */
+typedef struct bh_chain_storage {
+    long    nmodels;                      /* int(iterations * max(acceptance) / 100)              */
+    float  *models;                       /* [nchains][nmodels][2*(layers_max+1)]: vs.., z..      */
+    float  *misfits;                      /* [nchains][nmodels][ntargets+1]                       */
+    float  *likes;                        /* [nchains][nmodels]                                   */
+    float  *noise;                        /* [nchains][nmodels][2*ntargets]                       */
+    float  *vpvs;                         /* [nchains][nmodels]                                   */
+    double *iter;                         /* [nchains][nmodels]: iteration of acceptance          */
+} bh_chain_storage;
+
+int  bh_chains_create(const bh_chain_config *cfg, int nchains, const unsigned *seeds,
+                      const bh_chain_storage *storage, bh_chain_pool **pool);
+void bh_chains_destroy(bh_chain_pool *pool);
+int  bh_chains_set_threads(bh_chain_pool *pool, int nthreads);
+/* Draw the next proposal of every chain.  Chains whose proposal passed the prior checks are written
+ * compacted, k = 0..count-1: packed[k] = h, vp, vs, rho rows of Lmax doubles each (the layout
+ * bh_swd_batch takes with model_stride = 4*Lmax; rho = vp*0.32 + 0.77, src/Targets.py:319),
+ * nlay[k], noise[k][2*ntargets], chain[k] = the chain it belongs to.  Arrays hold nchains rows. */
+int  bh_chains_propose(bh_chain_pool *pool, int Lmax, double *packed, int *nlay, double *noise,
+                       int *chain, int *count);
+/* logL[count], misfits[count][ntargets+1] of the models handed out by the last propose: draw u,
+ * accept or reject, store, adapt the proposal widths, advance the iteration counter. */
+int  bh_chains_accept(bh_chain_pool *pool, const double *logL, const double *misfits);
+int  bh_chains_done(const bh_chain_pool *pool);            /* 1 when iiter reached iter_main  */
+long bh_chains_iteration(const bh_chain_pool *pool);       /* iiter, starts at -iter_burnin   */
+/* per-chain bookkeeping; any pointer may be NULL.  naccepted = rows stored so far (the reference's
+ * self.n), propdist[nchains][5], accepted/proposed[nchains][5] as in adjust_propdist */
+int  bh_chains_counters(const bh_chain_pool *pool, long *naccepted, double *propdist,
+                        double *accepted, double *proposed);
+/* current state of one chain: model = vs.., z.. (2*nnuclei doubles) */
+int  bh_chains_current(const bh_chain_pool *pool, int chain, int *nnuclei, double *model,
+                       double *noise, double *vpvs, double *like, double *misfits);
+/* The random stream of one chain, for tests and for adopting a numpy state
+ * (RandomState.get_state()): key[624], pos, has_gauss, cached_gaussian. */
+int  bh_chains_get_rng(const bh_chain_pool *pool, int chain, unsigned *key, int *pos,
+                       int *has_gauss, double *gauss);
+int  bh_chains_set_rng(bh_chain_pool *pool, int chain, const unsigned *key, int pos,
+                       int has_gauss, double gauss);
+/* n draws from the stream of one chain: kind 0 = uniform(a, b), 1 = normal(a, b),
+ * 2 = randint(a, b) (as doubles) -- numpy.random.RandomState's legacy algorithms */
+int  bh_chains_draw(bh_chain_pool *pool, int chain, int kind, double a, double b, int n,
+                    double *out);
+
 /* ---- plumbing for hosts without their own device allocator ------------------------------ */
 int bh_malloc(void **dptr, size_t bytes);
 int bh_free(void *dptr);

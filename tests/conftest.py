@@ -129,5 +129,10 @@ def golden():
             for name in ('swd_rf_random', 'swd_variants', 'rf_variants', 'tutorial_full')}
 
 
+@pytest.fixture(scope='session')
+def golden_chains():
+    return np.load(os.path.join(GOLDEN, 'chains_golden.npz'))
+
+
 REFS = [('rdispph', 2, 0), ('rdispgr', 2, 1), ('ldispph', 1, 0), ('ldispgr', 1, 1)]
 SETS = ['L%d_%s' % (L, s) for L in (2, 5, 10, 15, 31) for s in ('sorted', 'lvz')]

@@ -1,0 +1,52 @@
+"""Golden chains: the REFERENCE's own, unmodified sampler (src/SingleChain.py: SingleChain.run_chain,
+with src/Targets.py and src/Models.py, loaded file-wise by tests/scenarios/reference_chain.py) run in
+the development container on the tutorial's observed data, its forward plugins backed by the
+reference's native solvers (oracle/_ref, built from /root/reference by oracle/Makefile).
+
+    python tests/golden/make_golden_chains.py        (needs /root/reference and `make -C oracle ref`)
+
+For every set-up in tests/scenarios/chain_scenario.py::CASES and three seeds the file holds what the
+chain keeps: the accepted models, likelihoods, misfits, noise parameters, vp/vs (float32, as the
+reference stores them) and the iteration at which each was accepted.
+Output: chains_golden.npz (data only).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+
+
+def main():
+    import pyoracle
+    import reference_chain as rc
+    from chain_scenario import CASES, OraclePlugin
+    backend = 'ref' if pyoracle.have_ref() else 'port'
+    print('forward solvers:', backend)
+
+    class oracle(object):             # the module's functions, pinned to one back end
+        swd = staticmethod(lambda *a, **k: pyoracle.swd(*a, backend=backend, **k))
+        rf_model = staticmethod(lambda *a, **k: pyoracle.rf_model(*a, backend=backend, **k))
+    data = os.path.join(HERE, 'tutorial_observed')
+    out = {}
+    for name, case in sorted(CASES.items()):
+        seeds = [case['seed'], case['seed'] + 1, case['seed'] + 2]
+        out['%s/seeds' % name] = np.array(seeds)
+        for seed in seeds:
+            res = rc.run_chain(lambda xs, xr: (OraclePlugin(oracle, xs, 'swd'), OraclePlugin(oracle, xr, 'rf')),
+                               seed=seed, burnin=case['burnin'], main=case['main'], data_dir=data,
+                               priors=case['priors'], initparams=case['initparams'])
+            print(name, seed, 'accepted', res['n'], 'propdist', res['propdist'])
+            for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter', 'n', 'propdist', 'accepted', 'proposed'):
+                out['%s/%d/%s' % (name, seed, k)] = np.asarray(res[k])
+    np.savez_compressed(os.path.join(HERE, 'chains_golden.npz'), **out)
+    print('wrote chains_golden.npz', os.path.getsize(os.path.join(HERE, 'chains_golden.npz')), 'bytes')
+
+
+if __name__ == '__main__':
+    main()

@@ -67,9 +67,19 @@ def load_reference():
     return targets, chain.SingleChain
 
 
-def run_chain(make_plugins, seed=7, burnin=120, main=60, data_dir=None):
+TUTORIAL_PRIORS = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), mohoest=None,
+                       rfnoise_corr=0.9, swdnoise_corr=0., rfnoise_sigma=(1e-5, 0.05),
+                       swdnoise_sigma=(1e-5, 0.05))
+TUTORIAL_INITPARAMS = dict(nchains=1, propdist=(0.015, 0.015, 0.015, 0.005, 0.005), acceptance=(40, 45),
+                           thickmin=0.1, lvz=None, hvz=None, rcond=1e-5, station='test',
+                           savepath='results', maxmodels=50000)
+
+
+def run_chain(make_plugins, seed=7, burnin=120, main=60, data_dir=None, priors=None, initparams=None,
+              savepath=None):
     """Build the tutorial's joint target (Rayleigh phase + P-RF), install the plugins returned by
-    make_plugins(xsw, xrf) with the reference's update_plugin hook, run one reference chain."""
+    make_plugins(xsw, xrf) with the reference's update_plugin hook, run one reference chain.
+    With `savepath` the chain also writes its result files (SingleChain.save_finalmodels)."""
     T, SingleChain = load_reference()
     sw = np.loadtxt(os.path.join(data_dir, 'st3_rdispph.dat'))
     rf = np.loadtxt(os.path.join(data_dir, 'st3_prf.dat'))
@@ -79,25 +89,28 @@ def run_chain(make_plugins, seed=7, burnin=120, main=60, data_dir=None):
     t1.update_plugin(p1)
     t2.update_plugin(p2)
     joint = T.JointTarget(targets=[t1, t2])
-    priors = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), mohoest=None,
-                  rfnoise_corr=0.9, swdnoise_corr=0., rfnoise_sigma=(1e-5, 0.05),
-                  swdnoise_sigma=(1e-5, 0.05))
-    initparams = dict(nchains=1, iter_burnin=burnin, iter_main=main,
-                      propdist=(0.015, 0.015, 0.015, 0.005, 0.005), acceptance=(40, 45),
-                      thickmin=0.1, lvz=None, hvz=None, rcond=1e-5, station='test',
-                      savepath='results', maxmodels=50000)
-    nmodels = int((burnin + main) * 45 / 100.)
-    maxlayers = 21
+    pr = dict(TUTORIAL_PRIORS)
+    pr.update(priors or {})
+    ip = dict(TUTORIAL_INITPARAMS, iter_burnin=burnin, iter_main=main)
+    ip.update(initparams or {})
+    if savepath is not None:
+        ip['savepath'] = savepath
+        os.makedirs(os.path.join(savepath, 'data'), exist_ok=True)
+    nmodels = int((burnin + main) * max(ip['acceptance']) / 100.)
+    maxlayers = int(pr['layers'][1]) + 1
     f32 = np.float32
     shared = dict(sharedmodels=np.full(nmodels * maxlayers * 2, np.nan, dtype=f32),
                   sharedmisfits=np.full(nmodels * 3, np.nan, dtype=f32),
                   sharedlikes=np.full(nmodels, np.nan, dtype=f32),
                   sharednoise=np.full(nmodels * 4, np.nan, dtype=f32),
                   sharedvpvs=np.full(nmodels, np.nan, dtype=f32))
-    chain = SingleChain(targets=joint, chainidx=0, initparams=initparams, modelpriors=priors,
+    chain = SingleChain(targets=joint, chainidx=0, initparams=ip, modelpriors=pr,
                         random_seed=seed, **shared)
-    chain.save_finalmodels = lambda *a, **k: None          # no files
+    if savepath is None:
+        chain.save_finalmodels = lambda *a, **k: None          # no files
     chain.run_chain()
     return dict(models=np.array(chain.chainmodels), likes=np.array(chain.chainlikes),
                 misfits=np.array(chain.chainmisfits), noise=np.array(chain.chainnoise),
-                vpvs=np.array(chain.chainvpvs), n=chain.n)
+                vpvs=np.array(chain.chainvpvs), iter=np.array(chain.chainiter), n=chain.n,
+                propdist=np.array(chain.propdist), accepted=np.array(chain.accepted),
+                proposed=np.array(chain.proposed))

@@ -1,0 +1,174 @@
+"""Lock-step chain pool (bayhunter_amd/chains.py + csrc/chains.cpp), CPU tier.
+
+* the per-chain random streams are numpy.random.RandomState's, draw for draw;
+* with the same seed and the same forward values a pool chain IS the reference chain: where the
+  reference tree is available its own, unmodified SingleChain.run_chain() runs next to the pool
+  (both on the CPU oracle) and the stored samples, acceptance counters and adapted proposal widths
+  must be identical; the committed fixture tests/golden/chains_golden.npz (made by
+  tests/golden/make_golden_chains.py from the reference) repeats this without the reference tree;
+* the result files equal the ones the reference chain writes.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+import reference_chain as rc  # noqa: E402
+from chain_scenario import CASES, OraclePlugin, make_pool, oracle_evaluator  # noqa: E402
+
+DATA = os.path.join(GOLDEN, 'tutorial_observed')
+
+
+def _tiny_pool(lib, nchains=3, seeds=(0, 1, 12345)):
+    from bayhunter_amd import _lib
+    cfg = _lib.ChainConfig()
+    cfg.ntargets, cfg.layers_min, cfg.layers_max = 1, 1, 5
+    cfg.vs_min, cfg.vs_max, cfg.z_min, cfg.z_max = 2, 5, 0, 60
+    cfg.vpvs_fixed, cfg.vpvs_min, cfg.vpvs_max = 1, 1.73, 1.73
+    cfg.iter_burnin, cfg.iter_main = 10, 10
+    nm = 9
+    arrs = [np.full((nchains, nm, w), np.nan, dtype=np.float32) for w in (12, 2, 1, 2, 1)]
+    it = np.full((nchains, nm), np.nan)
+    st = _lib.ChainStorage()
+    st.nmodels = nm
+    for name, a in zip(('models', 'misfits', 'likes', 'noise', 'vpvs'), arrs):
+        setattr(st, name, a.ctypes.data)
+    st.iter = it.ctypes.data
+    seeds = np.asarray(seeds, dtype=np.uint32)
+    h = C.c_void_p()
+    _lib.check(lib.bh_chains_create(C.byref(cfg), nchains, seeds.ctypes.data, C.byref(st), C.byref(h)))
+    return h, (arrs, it, seeds)
+
+
+def test_random_streams_are_numpys(lib):
+    from bayhunter_amd import _lib
+    seeds = (0, 1, 12345, 999, 2**32 - 1)
+    h, keep = _tiny_pool(lib, len(seeds), seeds)
+    try:
+        for ci, seed in enumerate(seeds):
+            rs = np.random.RandomState(seed)
+            # interleave the three generators like a chain does; odd counts exercise the cached gaussian
+            for kind, a, b, n in ((0, 2.0, 5.0, 7), (1, 0.0, 0.015, 5), (2, 0, 6, 9), (1, 31.0, 2.5, 4),
+                                  (0, 0.0, 1.0, 3), (2, 4, 8, 5), (2, 0, 1, 2), (2, 0, 2**33 + 5, 6),
+                                  (1, 0.0, 1.0, 1001), (0, 1e-5, 0.05, 700)):
+                out = np.zeros(n)
+                _lib.check(lib.bh_chains_draw(h, ci, kind, float(a), float(b), n, out.ctypes.data))
+                if kind == 0:
+                    ref = np.array([rs.uniform(a, b) for _ in range(n)])
+                elif kind == 1:
+                    ref = np.array([rs.normal(a, b) for _ in range(n)])
+                else:
+                    ref = np.array([rs.randint(a, b) for _ in range(n)], dtype=np.float64)
+                assert np.array_equal(out, ref), (seed, kind, a, b)
+            # the state itself, and adopting a numpy state
+            key = np.zeros(624, dtype=np.uint32)
+            pos, hg, g = C.c_int(), C.c_int(), C.c_double()
+            _lib.check(lib.bh_chains_get_rng(h, ci, key.ctypes.data, C.byref(pos), C.byref(hg), C.byref(g)))
+            _, nkey, npos, nhg, ng = rs.get_state()
+            assert np.array_equal(key, nkey) and pos.value == npos and hg.value == nhg and g.value == ng
+        rs = np.random.RandomState(4242)
+        rs.normal(size=3)
+        _, nkey, npos, nhg, ng = rs.get_state()
+        nkey = np.ascontiguousarray(nkey, dtype=np.uint32)
+        _lib.check(lib.bh_chains_set_rng(h, 0, nkey.ctypes.data, int(npos), int(nhg), float(ng)))
+        out = np.zeros(5)
+        _lib.check(lib.bh_chains_draw(h, 0, 1, 0.0, 1.0, 5, out.ctypes.data))
+        assert np.array_equal(out, rs.normal(size=5))
+    finally:
+        lib.bh_chains_destroy(h)
+
+
+def test_protocol_errors(lib):
+    from bayhunter_amd import _lib
+    h, keep = _tiny_pool(lib)
+    try:
+        packed, nlay = np.zeros((3, 4, 8)), np.zeros(3, dtype=np.int32)
+        noise, chain, cnt = np.zeros((3, 2)), np.zeros(3, dtype=np.int32), C.c_int()
+        args = (packed.ctypes.data, nlay.ctypes.data, noise.ctypes.data, chain.ctypes.data, C.byref(cnt))
+        assert lib.bh_chains_accept(h, None, None) == _lib.BH_ERR_ARG             # nothing outstanding
+        assert lib.bh_chains_propose(h, 4, *args) == _lib.BH_ERR_ARG              # Lmax < layers_max + 1
+        assert b'Lmax' in lib.bh_last_error()
+        assert lib.bh_chains_propose(h, 8, *args) == _lib.BH_OK and cnt.value == 3
+        assert lib.bh_chains_propose(h, 8, *args) == _lib.BH_ERR_ARG              # results still due
+        assert list(nlay) == [2, 2, 2] and np.all(packed[:, 0, 1] == 0) and np.all(packed[:, 0, 0] > 0)
+        assert np.array_equal(packed[:, 3, :2], packed[:, 1, :2] * 0.32 + 0.77)
+        assert lib.bh_chains_done(h) == 0 and lib.bh_chains_iteration(h) == -10
+    finally:
+        lib.bh_chains_destroy(h)
+
+
+needs_ref = pytest.mark.skipif(not rc.available(), reason='reference tree not present')
+
+
+def _same(ref, got, name):
+    for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
+        assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
+
+
+@needs_ref
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_pool_chain_is_the_reference_chain(oracle, name):
+    case = CASES[name]
+    ref = rc.run_chain(lambda xs, xr: (OraclePlugin(oracle, xs, 'swd'), OraclePlugin(oracle, xr, 'rf')),
+                       seed=case['seed'], burnin=case['burnin'], main=case['main'], data_dir=DATA,
+                       priors=case['priors'], initparams=case['initparams'])
+    pool = make_pool(oracle, DATA, case, seeds=[case['seed']]).run()
+    got = pool.chain(0)
+    assert ref['n'] == got['n'] and got['n'] > 20
+    _same(ref, got, name)
+    n, propdist, accepted, proposed = pool.counters()
+    assert np.array_equal(propdist[0], ref['propdist'])
+    assert np.array_equal(accepted[0], ref['accepted']) and np.array_equal(proposed[0], ref['proposed'])
+
+
+def test_pool_chains_match_golden(oracle, golden_chains):
+    """Same comparison from the committed fixture (the reference tree is not needed): several
+    chains in ONE pool, two groups, so that lock step and grouping are covered too."""
+    for name in sorted(CASES):
+        case = CASES[name]
+        seeds = [int(s) for s in golden_chains['%s/seeds' % name]]
+        pool = make_pool(oracle, DATA, case, seeds=seeds, groups=2).run()
+        counts = pool.counters()[0]
+        for i, seed in enumerate(seeds):
+            got = pool.chain(i)
+            assert got['n'] == int(golden_chains['%s/%d/n' % (name, seed)]) == counts[i]
+            _same({k: golden_chains['%s/%d/%s' % (name, seed, k)] for k in
+                   ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter')}, got, (name, seed))
+
+
+def test_storage_overflow_is_reported(oracle):
+    case = dict(CASES['tutorial'], burnin=30, main=10)
+    case['initparams'] = dict(case['initparams'], acceptance=(1, 2))    # room for int(40*0.02) = 0 -> refuse
+    with pytest.raises(ValueError):
+        make_pool(oracle, DATA, case, seeds=[3])
+    case['initparams'] = dict(case['initparams'], acceptance=(3, 5))    # two rows: fills up quickly
+    from bayhunter_amd._lib import BayHunterAmdError
+    with pytest.raises(BayHunterAmdError, match='storage'):
+        make_pool(oracle, DATA, case, seeds=[3]).run()
+
+
+@needs_ref
+def test_result_files_equal_the_reference_chains(oracle, tmp_path):
+    case = CASES['tutorial']
+    refdir, mydir = str(tmp_path / 'ref'), str(tmp_path / 'mine')
+    rc.run_chain(lambda xs, xr: (OraclePlugin(oracle, xs, 'swd'), OraclePlugin(oracle, xr, 'rf')),
+                 seed=case['seed'], burnin=case['burnin'], main=case['main'], data_dir=DATA,
+                 priors=case['priors'], initparams=dict(case['initparams'], maxmodels=150), savepath=refdir)
+    case = dict(case, initparams=dict(case['initparams'], maxmodels=150))
+    pool = make_pool(oracle, DATA, case, seeds=[case['seed']]).run()
+    assert pool.save(mydir) == 10
+    files = sorted(f for f in os.listdir(os.path.join(refdir, 'data')) if f.endswith('.npy'))
+    assert len(files) == 10
+    for f in files:
+        a, b = np.load(os.path.join(refdir, 'data', f)), np.load(os.path.join(mydir, 'data', f))
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=True), f
+    import pickle
+    with open(os.path.join(mydir, 'data', 'test_config.pkl'), 'rb') as fh:
+        cfg = pickle.load(fh)
+    assert cfg['targetrefs'] == ['rdispph', 'prf'] and cfg['initparams']['maxmodels'] == 150
+    assert np.array_equal(cfg['targets'][0].obsdata.x, pool.targets.targets[0].obsdata.x)

@@ -1,0 +1,68 @@
+"""Chain pool on the GPU (`-m gpu`): bh_chains_* on the host cores, proposals evaluated by
+bh_swd_batch / bh_rf_batch / bh_likelihood_batch.  Compared with the committed chains of the
+reference's own sampler (tests/golden/chains_golden.npz, made by make_golden_chains.py).
+
+The device forward values differ from the reference's in the last bits (receiver functions <= 1e-15,
+LVZ dispersion <= the reference's own root bracket), so a chain is expected to make the SAME
+decisions -- identical accepted models and acceptance iterations -- with likelihoods and misfits
+equal to float32 storage precision.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+from chain_scenario import CASES, make_pool  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(GOLDEN, 'tutorial_observed')
+
+
+def gpu_evaluator(joint):
+    from bayhunter_amd.chains import GpuEvaluator
+    return GpuEvaluator(joint)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_gpu_pool_reproduces_reference_chains(golden_chains, name):
+    case = CASES[name]
+    seeds = [int(s) for s in golden_chains['%s/seeds' % name]]
+    pool = make_pool(None, DATA, case, seeds=seeds, groups=2, evaluator=gpu_evaluator).run()
+    for i, seed in enumerate(seeds):
+        got = pool.chain(i)
+        ref = {k: golden_chains['%s/%d/%s' % (name, seed, k)] for k in
+               ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter', 'n')}
+        assert got['n'] == int(ref['n']), (name, seed)
+        for k in ('models', 'noise', 'vpvs', 'iter'):
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (name, seed, k)
+        # float32 rows of float64 values that agree to ~1e-12: at most one float32 ulp apart
+        assert np.allclose(ref['likes'], got['likes'], rtol=3e-7, atol=0), (name, seed)
+        assert np.allclose(ref['misfits'], got['misfits'], rtol=3e-7, atol=0), (name, seed)
+        assert np.mean(ref['likes'] == got['likes']) > 0.99
+
+
+def test_gpu_pool_many_chains_lockstep_and_files(tmp_path):
+    """A pool large enough for two groups, threads and the lane kernel: chains with equal seeds are
+    equal whatever their position in the pool, and save() writes one file set per chain."""
+    case = dict(CASES['tutorial'], burnin=40, main=24)
+    seeds = list(range(100, 100 + 640)) + [100, 101, 739]
+    pool = make_pool(None, DATA, case, seeds=seeds, evaluator=gpu_evaluator).run()
+    assert len(pool.groups) == 2
+    n = pool.counters()[0]
+    assert n.min() >= 1 and pool.evaluated > 0.5 * len(seeds) * 64
+    for a, b in ((0, 640), (1, 641), (639, 642)):
+        ca, cb = pool.chain(a), pool.chain(b)
+        assert ca['n'] == cb['n']
+        for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
+            assert np.array_equal(ca[k], cb[k], equal_nan=True), (a, b, k)
+    small = make_pool(None, DATA, case, seeds=seeds[:3], evaluator=gpu_evaluator).run()
+    assert small.save(str(tmp_path)) >= 15
+    w = small.weighted(0)
+    assert w[1][0].shape[0] == 40 and w[2][0].shape[0] == 24       # one row per iteration
+    assert np.load(str(tmp_path / 'data' / 'c000_p2likes.npy')).shape == (24,)
+    for k in ('models', 'likes'):                                   # chain 0 of both pools: same seed
+        assert np.array_equal(small.chain(0)[k], pool.chain(0)[k], equal_nan=True)

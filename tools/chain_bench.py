@@ -1,0 +1,42 @@
+"""GPU box: throughput of the lock-step chain pool on the tutorial inversion (Rayleigh phase + P-RF,
+free vp/vs and noise) -- chain iterations per second end to end (host proposals + device forward
+and likelihood + host acceptance), for several pool sizes.
+usage: python tools/chain_bench.py [nchains ...]   -> one JSON line per pool size"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+
+
+def main():
+    from chain_scenario import CASES, joint_target
+    from bayhunter_amd.chains import ChainPool, GpuEvaluator
+    import torch
+    sizes = [int(a) for a in sys.argv[1:]] or [256, 1024, 4096, 16384]
+    data = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
+    case = CASES['tutorial']
+    for n in sizes:
+        iters = 120 if n <= 4096 else 60
+        joint = joint_target(data)
+        ip = dict(case['initparams'], iter_burnin=iters, iter_main=iters // 2, acceptance=(40, 100))
+        pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=np.arange(n) % 1000,
+                         evaluator=GpuEvaluator(joint))
+        t0 = time.perf_counter()
+        pool.run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        total = n * (iters + iters // 2)
+        acc = pool.counters()[0]
+        print(json.dumps(dict(nchains=n, iterations=iters + iters // 2, seconds=round(dt, 3),
+                              chain_iterations_per_s=round(total / dt), models_evaluated=int(pool.evaluated),
+                              mean_accepted=float(acc.mean()), groups=len(pool.groups))), flush=True)
+
+
+if __name__ == '__main__':
+    main()
