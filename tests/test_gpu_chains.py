@@ -49,6 +49,7 @@ def test_gpu_pool_many_chains_lockstep_and_files(tmp_path):
     """A pool large enough for two groups, threads and the lane kernel: chains with equal seeds are
     equal whatever their position in the pool, and save() writes one file set per chain."""
     case = dict(CASES['tutorial'], burnin=40, main=24)
+    case['initparams'] = dict(case['initparams'], acceptance=(40, 100))     # room for every iteration
     seeds = list(range(100, 100 + 640)) + [100, 101, 739]
     pool = make_pool(None, DATA, case, seeds=seeds, evaluator=gpu_evaluator).run()
     assert len(pool.groups) == 2
