@@ -22,6 +22,7 @@ and re-proposed on the host cores.
 import ctypes as C
 import os
 import pickle
+import time
 
 import numpy as np
 
@@ -61,14 +62,14 @@ class _CallEvaluator(object):
 class GpuEvaluator(object):
     """Proposals -> (logL, misfits) on the device through JointTarget.evaluate_batch.  Proposals are
     written by the library straight into pinned host buffers; upload, kernels and the download of
-    8*(ntargets+2) bytes per model are queued on one stream and `collect` waits for its event."""
+    8*(ntargets+2) bytes per model are queued on the group's own stream and `collect` waits for its
+    event, so the batches of different groups overlap on the device as far as it has room."""
 
     def __init__(self, joint, device=None):
         import torch
         self.torch = torch
         self.joint = joint
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
         self._pin = {}
 
     def buffers(self, rows, Lmax, ntargets):
@@ -80,7 +81,7 @@ class GpuEvaluator(object):
         outs = (torch.zeros(rows, dtype=torch.float64).pin_memory(),
                 torch.zeros((rows, ntargets + 1), dtype=torch.float64).pin_memory())
         views = tuple(b.numpy() for b in bufs)
-        self._pin[views[0].ctypes.data] = (bufs, outs)
+        self._pin[views[0].ctypes.data] = (bufs, outs, torch.cuda.Stream(device=self.device))
         return views
 
     def submit(self, group, packed, nlay, noise):
@@ -89,8 +90,8 @@ class GpuEvaluator(object):
         B = packed.shape[0]
         if B == 0:
             return None
-        bufs, outs = self._pin[packed.ctypes.data]
-        with torch.cuda.stream(self.stream):
+        bufs, outs, stream = self._pin[packed.ctypes.data]
+        with torch.cuda.stream(stream):
             dp = bufs[0][:B].to(self.device, non_blocking=True)
             dn = bufs[1][:B].to(self.device, non_blocking=True)
             dz = bufs[2][:B].to(self.device, non_blocking=True)
@@ -98,7 +99,7 @@ class GpuEvaluator(object):
             outs[0][:B].copy_(logL, non_blocking=True)
             outs[1][:B].copy_(misfits, non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record(self.stream)
+            ev.record(stream)
         return ev, outs, B
 
     def collect(self, ticket):
@@ -164,10 +165,14 @@ class ChainPool(object):
                  (packed[B,4,Lmax], nlay[B], noise[B,2*ntargets]) -> (logL[B], misfits[B,ntargets+1])
     groups       number of chain groups alternating between host and GPU (default 2 when the pool
                  has at least 512 chains, else 1)
+    shard        (rank, world): this process runs only its contiguous block of the nchains chains
+                 (distributed.shard_range), one process per GPU.  Seeds are drawn for ALL chains
+                 first, so chain c is the same chain whatever the number of ranks; chains never
+                 talk while sampling, `gather()` collects the sample blocks afterwards.
     """
 
     def __init__(self, targets, initparams=None, modelpriors=None, random_seed=None, nchains=None,
-                 seeds=None, evaluator=None, groups=None, nthreads=None):
+                 seeds=None, evaluator=None, groups=None, nthreads=None, shard=None):
         self.lib = _lib.load()
         self.targets = targets
         self.priors = dict(DEFAULT_PRIORS)
@@ -192,6 +197,13 @@ class ChainPool(object):
         self.seeds = np.asarray(seeds, dtype=np.uint32)
         if self.seeds.size != self.nchains:
             raise ValueError("one seed per chain")
+        self.nchains_total, self.first = self.nchains, 0
+        if shard is not None:
+            from .distributed import shard_range
+            lo, hi = shard_range(self.nchains, int(shard[0]), int(shard[1]))
+            if hi <= lo:
+                raise ValueError("rank %d of %d has no chain to run (nchains = %d)" % (shard[0], shard[1], self.nchains))
+            self.first, self.nchains, self.seeds = lo, hi - lo, self.seeds[lo:hi]
         self.cfg, corrfix, corr = self._config()
         # SingleChain._init_model_and_currentvalues -> set_target_covariance(corrfix[::2], inoise[::2], rcond):
         # a fixed correlation is the same number for every chain, a free one selects the exponential law
@@ -225,6 +237,9 @@ class ChainPool(object):
             for g in self.groups:
                 _lib.check(self.lib.bh_chains_set_threads(g.handle, int(nthreads)))
         self.evaluated = 0
+        # where run() spends its wall time: host proposal / launch calls / waiting for the device /
+        # host acceptance
+        self.seconds = dict(propose=0.0, submit=0.0, wait=0.0, accept=0.0)
         self._finished = False
 
     def __del__(self):
@@ -272,14 +287,23 @@ class ChainPool(object):
 
     # -- running -----------------------------------------------------------------------------
     def _launch(self, g):
+        t0 = time.perf_counter()
         n = g.propose()
+        t1 = time.perf_counter()
         self.evaluated += n
         g.ticket = self.evaluator.submit(g, g.packed[:n], g.nlay[:n], g.noise[:n])
+        t2 = time.perf_counter()
+        self.seconds['propose'] += t1 - t0
+        self.seconds['submit'] += t2 - t1
 
     def _land(self, g):
+        t0 = time.perf_counter()
         logL, misfits = self.evaluator.collect(g.ticket)
+        t1 = time.perf_counter()
         g.ticket = None
         g.accept(logL, misfits)
+        self.seconds['wait'] += t1 - t0
+        self.seconds['accept'] += time.perf_counter() - t1
 
     def run(self, progress=None):
         """Initial models, then iter_burnin + iter_main iterations of every chain."""
@@ -342,12 +366,29 @@ class ChainPool(object):
                           rep(ch['noise'], True), rep(ch['vpvs'], False))
         return out
 
-    def save(self, savepath=None, chainidx_offset=0):
+    def gather(self, group=None):
+        """All ranks' sample blocks -> dict of [nchains_total, nmodels, ...] arrays on every rank
+        (+ 'naccepted').  The one exchange of a multi-GPU run (the reference keeps these blocks in
+        shared memory, src/mcmcOptimizer.py:77-125): fixed-shape all_gather over RCCL, or gloo."""
+        import torch
+        import torch.distributed as dist
+        from .distributed import gather_rows
+        blocks = dict(models=self.models, misfits=self.misfits, likes=self.likes, noise=self.noise,
+                      vpvs=self.vpvs, iter=self.iter, naccepted=self.counters()[0])
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return blocks
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else 'cpu'
+        return {k: gather_rows(torch.from_numpy(np.ascontiguousarray(v)).to(dev), self.nchains_total, group).cpu().numpy()
+                for k, v in blocks.items()}
+
+    def save(self, savepath=None, chainidx_offset=None):
         """Write <savepath>/data/c%03d_p{1,2}{models,likes,misfits,noise,vpvs}.npy like
         SingleChain.save_finalmodels (:654-690), thinned to initparams['maxmodels'] main-phase
         models per chain, and <station>_config.pkl like utils.save_config (src/utils.py:127-153).
         (The reference's PlotFromStorage globs `c???_...`: it sees chain numbers up to 999.)"""
         savepath = savepath or self.initparams['savepath']
+        if chainidx_offset is None:
+            chainidx_offset = self.first          # a rank names its files by the global chain index
         data = os.path.join(savepath, 'data')
         os.makedirs(data, exist_ok=True)
         names = ('models', 'likes', 'misfits', 'noise', 'vpvs')

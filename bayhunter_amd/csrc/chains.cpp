@@ -18,11 +18,19 @@
 // from two outputs (a>>5, b>>6), the polar Box-Muller `legacy_gauss` with its cached second value,
 // and `randint` by masked rejection on 32-bit outputs.  The order of draws is the reference's, so a
 // chain here and a reference chain with the same seed see the same numbers.
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -134,18 +142,135 @@ enum Move { VSMOD = 0, ZVMOD = 1, BIRTH = 2, DEATH = 3, NOISE = 4, VPVS = 5 };
 const int PAR_OF_MOVE[6] = {0, 1, 2, 2, 3, 4};          // PAR_MAP, SingleChain.py:22-23
 const int MAXN = 2 * BH_MAX_TARGETS;
 
+// the four nuclei arrays of a chain live side by side in one arena of the pool
+struct Span {
+    double *p = nullptr;
+    double *data() { return p; }
+    const double *data() const { return p; }
+    double *begin() { return p; }
+    double &operator[](long i) { return p[i]; }
+    const double &operator[](long i) const { return p[i]; }
+};
+
 struct Chain {
     Rng rng;
     int n;                                   // nuclei of the current model
-    std::vector<double> vs, z;
+    Span vs, z;
     double noise[MAXN], vpvs, like, misfits[BH_MAX_TARGETS + 1];
     double propdist[5], accepted[5], proposed[5];
     long nstored, lastmoditer;
     // proposal of the running iteration
     int pn, move, valid, slot;
-    std::vector<double> pvs, pz;
+    Span pvs, pz;
     double pnoise[MAXN], pvpvs, dvs2;
 };
+
+// Persistent helper threads: propose/accept run once per iteration over a few thousand chains, too
+// short to pay for thread creation -- or even for a futex wake-up (hundreds of microseconds on a
+// virtualised host) -- every time.  A worker therefore spins on the job counter for a while after
+// its last job (the next call normally follows within the time the GPU needs for the other group)
+// and only then goes to sleep on the condition variable.
+class Workers {
+public:
+    Workers()
+    {
+        if (const char *e = std::getenv("BH_CHAIN_SPIN_US")) spin_us_ = std::max(0, std::atoi(e));
+    }
+    ~Workers()
+    {
+        stop_.store(true);
+        gen_.fetch_add(1);
+        { std::lock_guard<std::mutex> lk(m_); }
+        start_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // f(i) for i in [0, nitems), split into `parts` contiguous blocks; the caller works on block 0
+    void run(int nitems, int parts, const std::function<void(int)> &f)
+    {
+        if (parts <= 1) {
+            for (int i = 0; i < nitems; i++) f(i);
+            return;
+        }
+        while ((int)th_.size() < parts - 1) {
+            int id = (int)th_.size() + 1;
+            th_.emplace_back([this, id]() { loop(id); });
+        }
+        f_ = &f; nitems_ = nitems; parts_ = parts;
+        pending_.store(parts - 1);
+        gen_.fetch_add(1);                       // publishes the job (seq_cst)
+        { std::lock_guard<std::mutex> lk(m_); }  // a worker about to sleep has either seen it or waits
+        start_.notify_all();
+        block(0);
+        while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
+    }
+
+private:
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    void block(int id)
+    {
+        int per = (nitems_ + parts_ - 1) / parts_;
+        int lo = id * per, hi = std::min(nitems_, lo + per);
+        for (int i = lo; i < hi; i++) (*f_)(i);
+    }
+    void loop(int id)
+    {
+        long seen = 0;
+        for (;;) {
+            auto t0 = std::chrono::steady_clock::now();
+            int polls = 0;
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                cpu_relax();
+                if (++polls == 256) {
+                    polls = 0;
+                    auto waited = std::chrono::duration_cast<std::chrono::microseconds>(
+                        std::chrono::steady_clock::now() - t0).count();
+                    if (waited > spin_us_) {
+                        std::unique_lock<std::mutex> lk(m_);
+                        start_.wait(lk, [&]() { return gen_.load() != seen; });
+                    }
+                }
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            if (stop_.load()) return;
+            // a worker may lag one job behind only if it was not part of it, so `parts_` is current
+            if (id < parts_) {
+                block(id);
+                pending_.fetch_sub(1, std::memory_order_release);
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable start_;
+    const std::function<void(int)> *f_ = nullptr;
+    int nitems_ = 0, parts_ = 0;
+    std::atomic<int> pending_{0};
+    std::atomic<long> gen_{0};
+    std::atomic<bool> stop_{false};
+    long spin_us_ = 2000;
+};
+
+int default_threads()
+{
+    // the cores this process may run on, at most 16 (a GPU box gives one GPU a 16-core share of a
+    // much larger machine); BH_CHAIN_THREADS overrides
+    if (const char *e = std::getenv("BH_CHAIN_THREADS")) {
+        int v = std::atoi(e);
+        if (v > 0) return v;
+    }
+    cpu_set_t set;
+    int n = 0;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n < 1) n = (int)std::max(1u, std::thread::hardware_concurrency());
+    return std::min(n, 16);
+}
 
 }  // namespace
 
@@ -159,26 +284,20 @@ struct bh_chain_pool {
     int count, failed;
     std::vector<int> noiseinds;
     std::vector<Chain> chains;
+    std::vector<double> arena;
 };
 
 namespace {
 
-template <class F>
-void for_chains(bh_chain_pool *p, F f)
+void for_chains(bh_chain_pool *p, const std::function<void(int)> &f)
 {
-    int nt = std::max(1, std::min(p->nthreads, p->nchains / 256));
-    if (nt == 1) {
-        for (int i = 0; i < p->nchains; i++) f(i);
-        return;
-    }
-    std::vector<std::thread> th;
-    int per = (p->nchains + nt - 1) / nt;
-    for (int t = 0; t < nt; t++) {
-        int lo = t * per, hi = std::min(p->nchains, lo + per);
-        if (lo >= hi) break;
-        th.emplace_back([=]() { for (int i = lo; i < hi; i++) f(i); });
-    }
-    for (auto &t : th) t.join();
+    // One set of helper threads for the whole process: the groups of a ChainPool take turns on the
+    // host, and two sets of spinning workers would fight for the same cores.  A block of fewer than
+    // ~128 chains is not worth a thread.
+    static Workers workers;
+    static std::mutex turn;
+    std::lock_guard<std::mutex> lk(turn);
+    workers.run(p->nchains, std::max(1, std::min(p->nthreads, p->nchains / 128)), f);
 }
 
 // Model.get_vp_vs_h: interfaces midway between neighbouring nuclei, half space h = 0
@@ -265,7 +384,7 @@ void initial_model(bh_chain_pool *p, Chain &c)
     int n = g.layers_min + 1;
     for (;;) {
         for (int i = 0; i < n; i++) c.pvs[i] = c.rng.uniform(g.vs_min, g.vs_max);
-        std::sort(c.pvs.begin(), c.pvs.begin() + n);
+        std::sort(c.pvs.data(), c.pvs.data() + n);
         if (g.has_mohoest && n > 1) {
             double moho = c.rng.normal(g.moho_mean, g.moho_std);
             double half = c.rng.uniform(1, std::min(5.0, moho));
@@ -275,7 +394,7 @@ void initial_model(bh_chain_pool *p, Chain &c)
         } else {
             for (int i = 0; i < n; i++) c.pz[i] = c.rng.uniform(g.z_min, g.z_max);
         }
-        std::sort(c.pz.begin(), c.pz.begin() + n);
+        std::sort(c.pz.data(), c.pz.data() + n);
         if (valid_model(g, n, c.pvs.data(), c.pz.data())) break;
     }
     c.pn = n;
@@ -299,7 +418,7 @@ void propose(bh_chain_pool *p, Chain &c)
     int n = c.n;
     std::memcpy(c.pvs.data(), c.vs.data(), n * sizeof(double));
     std::memcpy(c.pz.data(), c.z.data(), n * sizeof(double));
-    std::memcpy(c.pnoise, c.noise, sizeof(c.noise));
+    std::memcpy(c.pnoise, c.noise, 2 * g.ntargets * sizeof(double));
     c.pvpvs = c.vpvs;
     c.pn = n;
     c.valid = 1;
@@ -382,7 +501,7 @@ void take_proposal(bh_chain_pool *p, Chain &c, const double *logL, const double 
     c.n = c.pn;
     std::memcpy(c.vs.data(), c.pvs.data(), c.pn * sizeof(double));
     std::memcpy(c.z.data(), c.pz.data(), c.pn * sizeof(double));
-    std::memcpy(c.noise, c.pnoise, sizeof(c.noise));
+    std::memcpy(c.noise, c.pnoise, 2 * T * sizeof(double));
     c.vpvs = c.pvpvs;
     c.lastmoditer = p->iiter;
 }
@@ -451,7 +570,7 @@ int bh_chains_create(const bh_chain_config *cfg, int nchains, const unsigned *se
     p->st = *st;
     p->nchains = nchains;
     p->maxl = cfg->layers_max + 1;
-    p->nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    p->nthreads = default_threads();
     p->iterations = cfg->iter_burnin + cfg->iter_main;
     p->iiter = -cfg->iter_burnin;
     p->stage = 0;
@@ -460,12 +579,14 @@ int bh_chains_create(const bh_chain_config *cfg, int nchains, const unsigned *se
     for (int i = 0; i < 2 * cfg->ntargets; i++)
         if (!cfg->noise_fixed[i]) p->noiseinds.push_back(i);
     p->chains.resize(nchains);
+    const long W = p->maxl + 2;
+    p->arena.assign((size_t)nchains * 4 * W, 0.0);
     for (int i = 0; i < nchains; i++) {
         Chain &c = p->chains[i];
         c.rng.seed(seeds[i]);
         c.n = 0;
-        c.vs.assign(p->maxl + 2, 0.0); c.z.assign(p->maxl + 2, 0.0);
-        c.pvs.assign(p->maxl + 2, 0.0); c.pz.assign(p->maxl + 2, 0.0);
+        double *a = p->arena.data() + (size_t)i * 4 * W;
+        c.vs.p = a; c.z.p = a + W; c.pvs.p = a + 2 * W; c.pz.p = a + 3 * W;
         std::memset(c.noise, 0, sizeof(c.noise)); std::memset(c.pnoise, 0, sizeof(c.pnoise));
         std::memset(c.misfits, 0, sizeof(c.misfits));
         c.vpvs = c.pvpvs = 0.0; c.like = 0.0; c.dvs2 = 0.0;

@@ -109,8 +109,9 @@ class ForwardEngine(object):
         with torch.cuda.device(self.device):
             self.periods = torch.from_numpy(
                 np.concatenate(pers) if pers else np.zeros(1)).to(self.device)
-        self._ws = None
-        self._side = None        # side stream: RF back-fills the SIMDs the SWD tail leaves idle
+        # per launch stream (batches may be in flight on several streams at once, chains.GpuEvaluator):
+        self._ws = {}            # workspace of bh_swd_batch
+        self._side = {}          # side stream: RF back-fills the SIMDs the SWD tail leaves idle
         self.overlap = True
         self.sort_ragged = True  # re-order ragged batches by layer count at upload
 
@@ -168,17 +169,19 @@ class ForwardEngine(object):
             # the freed SIMDs instead of waiting for the last search to finish.
             side = None
             if self.swd and self._rfp and self.overlap:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                side = self._side
+                side = self._side.get(st.cuda_stream)
+                if side is None:
+                    side = self._side[st.cuda_stream] = torch.cuda.Stream(device=self.device)
                 side.wait_stream(st)
             if self.swd:
                 need = self.lib.bh_swd_workspace_bytes(B, len(self.swd), self._tg)
                 ws_ptr = None
                 if need:
-                    if self._ws is None or self._ws.numel() * 8 < need:
-                        self._ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=self.device)
-                    ws_ptr = self._ws.data_ptr()
+                    ws = self._ws.get(st.cuda_stream)
+                    if ws is None or ws.numel() * 8 < need:
+                        ws = self._ws[st.cuda_stream] = torch.empty((need + 7) // 8, dtype=torch.float64,
+                                                                    device=self.device)
+                    ws_ptr = ws.data_ptr()
                 _lib.check(self.lib.bh_swd_batch(
                     B, Lmax, mstride, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
                     RHO.data_ptr(), len(self.swd), self._tg, self.periods.data_ptr(),

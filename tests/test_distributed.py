@@ -71,3 +71,46 @@ def test_gloo_world2_gather_equals_single_process(oracle, n):
     assert full.shape == (n, 12)
     assert np.array_equal(full[:, :11], out) and np.array_equal(full[:, 11], err)
     assert t == 2.0
+
+
+def _chain_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    from chain_scenario import CASES, OraclePlugin, joint_target, oracle_evaluator
+    from bayhunter_amd.chains import ChainPool
+    case = CASES['fixednoise']
+    data = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
+    joint = joint_target(data, lambda xs, xr: (OraclePlugin(po, xs, 'swd'), OraclePlugin(po, xr, 'rf')))
+    ip = dict(case['initparams'], iter_burnin=case['burnin'], iter_main=case['main'])
+    pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=[5, 6, 7], shard=(rank, world),
+                     evaluator=oracle_evaluator(joint)).run()
+    full = pool.gather()
+    if rank == 0:
+        q.put((pool.first, pool.nchains, full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_chain_pool_shards_and_gathers(golden_chains):
+    """Three chains over two ranks (2 + 1): every rank runs its block with the global seeds, the
+    gathered sample blocks equal the reference's chains, chain by chain."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chain_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    first, mine, full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (first, mine) == (0, 2) and full['likes'].shape[0] == 3
+    for i, seed in enumerate((5, 6, 7)):
+        n = int(golden_chains['fixednoise/%d/n' % seed])
+        assert int(full['naccepted'][i]) == n
+        for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
+            assert np.array_equal(full[k][i, :n], golden_chains['fixednoise/%d/%s' % (seed, k)], equal_nan=True), (seed, k)

@@ -22,11 +22,12 @@ def main():
     data = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
     case = CASES['tutorial']
     for n in sizes:
-        iters = 120 if n <= 4096 else 60
+        iters = int(os.environ.get('CHAIN_BENCH_ITERS', 120 if n <= 4096 else 60))
         joint = joint_target(data)
         ip = dict(case['initparams'], iter_burnin=iters, iter_main=iters // 2, acceptance=(40, 100))
         pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=np.arange(n) % 1000,
-                         evaluator=GpuEvaluator(joint))
+                         evaluator=GpuEvaluator(joint),
+                         groups=int(os.environ['CHAIN_BENCH_GROUPS']) if 'CHAIN_BENCH_GROUPS' in os.environ else None)
         t0 = time.perf_counter()
         pool.run()
         torch.cuda.synchronize()
@@ -35,7 +36,8 @@ def main():
         acc = pool.counters()[0]
         print(json.dumps(dict(nchains=n, iterations=iters + iters // 2, seconds=round(dt, 3),
                               chain_iterations_per_s=round(total / dt), models_evaluated=int(pool.evaluated),
-                              mean_accepted=float(acc.mean()), groups=len(pool.groups))), flush=True)
+                              mean_accepted=float(acc.mean()), groups=len(pool.groups),
+                              seconds_in={k: round(v, 3) for k, v in pool.seconds.items()})), flush=True)
 
 
 if __name__ == '__main__':
