@@ -111,7 +111,7 @@ int g_swd_mode = BH_SWD_AUTO;
 long team_threshold()
 {
     static const char *e = std::getenv("BH_SWD_TEAM_MAX");
-    return e ? std::atol(e) : 8192;    // measured crossover on MI355X
+    return e ? std::atol(e) : 12288;   // measured crossover on MI355X
 }
 
 int pick_rf_M(int B, int Lmax, int nsamp)
@@ -153,7 +153,7 @@ int bh_set_device(int device)
 
 int bh_swd_set_kernel(int mode)
 {
-    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM) return fail_arg("unknown kernel mode");
+    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM16) return fail_arg("unknown kernel mode");
     g_swd_mode = mode;
     return BH_OK;
 }
@@ -205,10 +205,17 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
     if (rc) return rc;
     // Few searches: spend a whole wave on each (swd_team.h, ~10x lower latency); many: one lane
     // each (swd_lane, ~5x more searches per second).  bh_swd_set_kernel overrides.
-    bool team = (long)B * ntargets <= (long)team_threshold();
+    // measured on MI355X (profiles/r01_team_widths.txt, 3-15 layers): up to 2048 searches a whole
+    // wave each, up to 4096 half a wave, up to the lane kernel's crossover a quarter
+    const long searches = (long)B * ntargets;
+    bool team = searches <= (long)team_threshold();
+    int width = searches <= 2048 ? 64 : searches <= 4096 ? 32 : 16;
     if (g_swd_mode == BH_SWD_LANE) team = false;
-    if (g_swd_mode == BH_SWD_TEAM) team = true;
-    if (team) BH_HIP(bh::launch_swd_team(A, (hipStream_t)stream));
+    if (g_swd_mode >= BH_SWD_TEAM) {
+        team = true;
+        width = g_swd_mode == BH_SWD_TEAM16 ? 16 : g_swd_mode == BH_SWD_TEAM32 ? 32 : 64;
+    }
+    if (team) BH_HIP(bh::launch_swd_team(A, width, (hipStream_t)stream));
     else BH_HIP(bh::launch_swd(A, resident, (hipStream_t)stream));
     return BH_OK;
 }

@@ -128,7 +128,7 @@ struct TeamLay {
 struct TeamSrc {
     const SwdArgs &A;
     const SwdTargetDev &tg;
-    int t, lane, taken;
+    int t, lane, nlanes, taken;
     long b;
     __device__ __forceinline__ int next(TeamLay &lay, double *&out, double *&cws, double *&cbws)
     {
@@ -138,7 +138,7 @@ struct TeamSrc {
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         const long g = b * A.mstride;
-        for (int l = lane; l < nl; l += SWD_T) {
+        for (int l = lane; l < nl; l += nlanes) {
             lay.set_d(l, (float)A.h[g + l]);
             lay.set_a(l, (float)A.vp[g + l]);
             lay.set_b(l, (float)A.vs[g + l]);
@@ -158,32 +158,77 @@ struct TeamSrc {
     }
 };
 
-__global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A)
+// TEAM lanes per search, 64/TEAM searches per wave (workgroup = one wave).  TEAM = 64 is the lowest
+// latency (most speculation); narrower teams waste fewer lanes in the sequential refinement rounds
+// (1 trial x (L-1) layer matrices) and on shallow models, i.e. more searches per second.  The teams
+// of a wave run the same phases between the barriers; a team whose search is over idles until the
+// last one is done.  (__syncthreads in a one-wave workgroup is an LDS fence, also under divergence.)
+template <int TEAM>
+__device__ __forceinline__ void swd_team_body(const SwdArgs &A)
 {
     extern __shared__ double tlds[];
-    const int lane = threadIdx.x;
+    constexpr int NSUB = SWD_T / TEAM;
+    const int sub = NSUB == 1 ? 0 : threadIdx.x / TEAM, lane = NSUB == 1 ? threadIdx.x : threadIdx.x % TEAM;
     const int t = blockIdx.y;
     const SwdTargetDev tg = A.tg[t];
-    const int nm = A.Lmax > SWD_T ? A.Lmax : SWD_T;
-    double *mats = tlds, *trials = tlds + (long)nm * SWD_NCA, *dels = trials + SWD_TEAM_NT;
+    const int nm = A.Lmax > TEAM ? A.Lmax : TEAM;
+    // per team: mats[nm][19], trials[16], dels[16] (doubles), then 4*Lmax floats (padded to doubles)
+    const int per_team = nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * A.Lmax + 1) / 2;
+    double *mats = tlds + (long)sub * per_team, *trials = mats + (long)nm * SWD_NCA, *dels = trials + SWD_TEAM_NT;
     TeamLay lay{(float *)(dels + SWD_TEAM_NT), A.Lmax};
-    TeamSrc src{A, tg, t, lane, 0, (long)blockIdx.x};
+    const long b = (long)blockIdx.x * NSUB + sub;
+    TeamSrc src{A, tg, t, lane, TEAM, (NSUB == 1 || b < A.B) ? 0 : 1, b};
     const double *per = A.periods + tg.per_off;
     SwdState S;
     swd_state_init(S);
-    for (;;) {
-        swd_driver(S, lay, src, tg, per, A.B);
-        if (S.st == SWD_ST_DONE) break;
-        const int nt = swd_team_plan(S, SWD_T, trials);
-        __syncthreads();
-        swd_team_assemble(lay, lane, SWD_T, tg.iwave, S, nt, trials, mats);
-        __syncthreads();
-        if (tg.iwave == 2 && nt <= 8) swd_team_chain_ray5(lay, lane, S, nt, trials, mats, dels);
-        else swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
-        __syncthreads();
-        swd_team_consume(S, nt, trials, dels);
-        __syncthreads();
+    if constexpr (NSUB == 1) {
+        for (;;) {
+            swd_driver(S, lay, src, tg, per, A.B);
+            if (S.st == SWD_ST_DONE) break;
+            const int nt = swd_team_plan(S, TEAM, trials);
+            __syncthreads();
+            swd_team_assemble(lay, lane, TEAM, tg.iwave, S, nt, trials, mats);
+            __syncthreads();
+            if (tg.iwave == 2 && nt <= 8) swd_team_chain_ray5(lay, lane, S, nt, trials, mats, dels);
+            else swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
+            __syncthreads();
+            swd_team_consume(S, nt, trials, dels);
+            __syncthreads();
+        }
+    } else {
+        // A team whose search is over keeps walking through the phases with nt = 0 (no trial, no
+        // matrix, no value consumed): cheaper than predicating every phase on a per-team flag.
+        bool live = true;
+        for (;;) {
+            if (live) {
+                swd_driver(S, lay, src, tg, per, A.B);
+                live = S.st != SWD_ST_DONE;
+            }
+            if (!__any(live)) break;
+            const int nt = live ? swd_team_plan(S, TEAM, trials) : 0;
+            __syncthreads();
+            swd_team_assemble(lay, lane, TEAM, tg.iwave, S, nt, trials, mats);
+            __syncthreads();
+            if (tg.iwave == 2 && 8 * nt <= TEAM) swd_team_chain_ray5(lay, lane, S, nt, trials, mats, dels);
+            else swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
+            __syncthreads();
+            swd_team_consume(S, nt, trials, dels);
+            __syncthreads();
+        }
     }
+}
+
+// The 64-lane form fits 256 VGPRs as it is (2 waves per SIMD).  The narrower forms carry per-team
+// liveness through the divergent driver call and want ~310 registers: pinned to 2 waves per SIMD
+// they spill ~50 dwords and are still 1.3-1.4x faster than at one wave per SIMD (measured).
+__global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A) { swd_team_body<64>(A); }
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team32_kernel(SwdArgs A)
+{
+    swd_team_body<32>(A);
+}
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team16_kernel(SwdArgs A)
+{
+    swd_team_body<16>(A);
 }
 
 // -------------------------------------------------------------------------------------------- RF
@@ -294,14 +339,17 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
 }
 
 // ---------------------------------------------------------------------------------------- launch
-hipError_t launch_swd_team(const SwdArgs &A, hipStream_t stream)
+hipError_t launch_swd_team(const SwdArgs &A, int team, hipStream_t stream)
 {
-    size_t lds = (size_t)swd_team_lds_doubles(A.Lmax, SWD_T) * sizeof(double) +
-                 (size_t)4 * A.Lmax * sizeof(float);
-    static size_t lds_set[16] = {0};
-    hipError_t e = ensure_dyn_lds((const void *)swd_team_kernel, lds, lds_set);
+    if (team != 16 && team != 32) team = 64;
+    const int nsub = SWD_T / team;
+    const int nm = A.Lmax > team ? A.Lmax : team;
+    size_t lds = (size_t)nsub * (nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * A.Lmax + 1) / 2) * sizeof(double);
+    static size_t lds_set[3][16] = {{0}, {0}, {0}};
+    void (*kern)(SwdArgs) = team == 16 ? swd_team16_kernel : team == 32 ? swd_team32_kernel : swd_team_kernel;
+    hipError_t e = ensure_dyn_lds((const void *)kern, lds, lds_set[team == 16 ? 2 : team == 32 ? 1 : 0]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(swd_team_kernel, dim3(A.B, A.ntargets), dim3(SWD_T), lds, stream, A);
+    hipLaunchKernelGGL(kern, dim3((A.B + nsub - 1) / nsub, A.ntargets), dim3(SWD_T), lds, stream, A);
     return hipGetLastError();
 }
 

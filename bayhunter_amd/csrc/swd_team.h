@@ -129,13 +129,14 @@ BH_DEV void swd_team_chain(const Lay &lay, int lane, int ifunc, const SwdState &
 // lanes 8j .. 8j+4 serve trial j.  Lane i forms ee_i = sum_k e_k*ca(k,i) in the reference's order
 // from its column of the layer matrix, the group max-reduces |ee_i| (normc), every lane divides its
 // own component with the shared reciprocal and the new vector is re-gathered by shuffles.
-// Requires nt <= 8 and all 64 lanes of the wave active.
+// `lane` is the lane within the team (8 | team width, teams aligned in the wave); requires
+// 8*nt <= team width and every lane of the team active.
 template <class Lay>
 __device__ __forceinline__ void swd_team_chain_ray5(const Lay &lay, int lane, const SwdState &S,
                                                     int nt, const double *trials, const double *mats,
                                                     double *dels)
 {
-    const int j = lane >> 3, i = lane & 7, gbase = lane & ~7;
+    const int j = lane >> 3, i = lane & 7, gbase = (int)(threadIdx.x & 63) & ~7;
     const bool live = (j < nt) && (i < 5);
     const int nlm = S.mmax - S.llw;
     const double wvno = S.omega / trials[j < nt ? j : 0];

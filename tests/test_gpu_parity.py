@@ -249,17 +249,18 @@ def test_full_size_properties(lib, oracle):
     assert np.abs(o[sl, eng.slices[4]] - oracle.rf_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl])).max() <= TOL_RF
 
 
-@pytest.fixture
-def team_mode(lib):
+@pytest.fixture(params=['team', 'team32', 'team16'])
+def team_mode(lib, request):
     from bayhunter_amd import _lib
-    _lib.set_swd_kernel('team')
+    _lib.set_swd_kernel(request.param)
     yield
     _lib.set_swd_kernel('auto')
 
 
 @pytest.mark.parametrize('tag', ['L2_sorted', 'L10_sorted', 'L10_lvz', 'L31_lvz', 'ragged'])
 def test_team_kernel_golden_sets(lib, golden, team_mode, tag):
-    """The latency kernel (one wave per search) against the golden vectors, same tolerances."""
+    """The latency kernels (64, 32 or 16 lanes per search) against the golden vectors, same
+    tolerances."""
     g = golden['swd_rf_random']
     H, VP, VS, RHO = g[tag + '_model']
     nl = g['ragged_nlay'] if tag == 'ragged' else _nlay(g[tag + '_model'])
@@ -282,7 +283,7 @@ def test_team_and_lane_kernels_agree_bitwise(lib, oracle):
              (draw_models(6, 100, seed=14, zmax=300.0, thickmin=0.05), dict())]
     for (H, VP, VS, RHO, nl), kw in cases:
         res = {}
-        for mode in ('lane', 'team'):
+        for mode in ('lane', 'team', 'team32', 'team16'):
             _lib.set_swd_kernel(mode)
             try:
                 eng = _engine([r[0] for r in REFS], per, **kw)
@@ -290,8 +291,9 @@ def test_team_and_lane_kernels_agree_bitwise(lib, oracle):
                 res[mode] = (out.cpu().numpy(), err.cpu().numpy())
             finally:
                 _lib.set_swd_kernel('auto')
-        assert np.array_equal(res['lane'][1], res['team'][1])
-        assert np.array_equal(res['lane'][0], res['team'][0])
+        for mode in ('team', 'team32', 'team16'):
+            assert np.array_equal(res['lane'][1], res[mode][1]), mode
+            assert np.array_equal(res['lane'][0], res[mode][0]), mode
         if not kw:
             want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, 2, 0)
             assert np.array_equal(res['team'][1][:, 0], werr)

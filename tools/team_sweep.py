@@ -21,10 +21,15 @@ def run(B, L, refs, P, mode, reps=3):
     _lib.set_swd_kernel('auto')
     return (time.perf_counter() - t0) / reps * 1e3
 
-for L, refs, P in ((10, ['rdispph'], 21), (5, ['rdispph'], 20), (15, ['rdispph'], 21),
+MODES = ('lane', 'team', 'team32', 'team16')
+QUICK = os.environ.get('SWEEP_QUICK')
+for L, refs, P in ((3, ['rdispph'], 21), (5, ['rdispph'], 21), (10, ['rdispph'], 21), (15, ['rdispph'], 21),
                    (10, ['rdispph', 'rdispgr', 'ldispph', 'ldispgr'], 40)):
-    for B in (64, 256, 1024, 4096, 8192, 16384, 32768, 65536):
+    for B in (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
         if len(refs) == 4 and B > 16384: continue
-        tl, tt = run(B, L, refs, P, 'lane'), run(B, L, refs, P, 'team')
-        print('L=%2d targets=%d P=%d B=%6d  lane %8.2f ms  team %8.2f ms  -> %s' % (L, len(refs), P, B, tl, tt, 'team' if tt < tl else 'lane'))
+        if QUICK and (B not in (1024, 4096, 8192) or L in (5, 15)): continue
+        ts = [run(B, L, refs, P, m) for m in MODES]
+        best = MODES[int(np.argmin(ts))]
+        print('L=%2d targets=%d P=%d B=%6d  ' % (L, len(refs), P, B) +
+              '  '.join('%s %8.2f ms' % (m, t) for m, t in zip(MODES, ts)) + '  -> ' + best)
         sys.stdout.flush()
