@@ -145,6 +145,34 @@ def n_dltar_sample(wl):
 
 
 # ----------------------------------------------------------------------------------------- main
+def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
+    """End-to-end sampler on top of the timed path (not part of `value`): a lock-step pool of
+    chains on the tutorial inversion (Rayleigh phase + P-RF, observed data in
+    tests/golden/tutorial_observed), chain iterations per second incl. host proposals/acceptance."""
+    try:
+        import torch
+        from bayhunter_amd import targets as T
+        from bayhunter_amd.chains import ChainPool
+        d = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
+        sw, rf = np.loadtxt(os.path.join(d, 'st3_rdispph.dat')), np.loadtxt(os.path.join(d, 'st3_prf.dat'))
+        joint = T.JointTarget([T.RayleighDispersionPhase(sw[:, 0], sw[:, 1]), T.PReceiverFunction(rf[:, 0], rf[:, 1])])
+        priors = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), mohoest=None, rfnoise_corr=0.9,
+                      swdnoise_corr=0., rfnoise_sigma=(1e-5, 0.05), swdnoise_sigma=(1e-5, 0.05))
+        ip = dict(iter_burnin=burnin, iter_main=main_it, propdist=(0.015, 0.015, 0.015, 0.005, 0.005),
+                  acceptance=(40, 100), thickmin=0.1, rcond=1e-5)
+        pool = ChainPool(joint, initparams=ip, modelpriors=priors, seeds=np.arange(nchains) % 1000)
+        t0 = time.perf_counter()
+        pool.run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": nchains * (burnin + main_it) / dt, "unit": "chain iterations/s", "nchains": nchains,
+                "iterations": burnin + main_it, "models_evaluated": int(pool.evaluated),
+                "workload": "tutorial joint inversion (rdispph + prf), free vp/vs and noise, 2-21 layers",
+                "host_seconds": {k: round(v, 4) for k, v in pool.seconds.items()}}
+    except Exception as e:            # the sample must never take the benchmark line down
+        return {"value": None, "error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -154,6 +182,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='models per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true')
+    ap.add_argument('--no-chain-pool', action='store_true')
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
@@ -284,6 +313,8 @@ def main():
                            "note": "serialised; in the timed steps rf_kernel runs on a second stream and back-fills the tail of swd_kernel"},
             "cpu_baseline": cpu,
         }
+        if world == 1 and args.workload == 'joint10' and not args.no_chain_pool:
+            res["chain_pool"] = chain_pool_sample()
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
