@@ -19,6 +19,7 @@
 // and `randint` by masked rejection on 32-bit outputs.  The order of draws is the reference's, so a
 // chain here and a reference chain with the same seed see the same numbers.
 #include <sched.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -294,10 +295,17 @@ void for_chains(bh_chain_pool *p, const std::function<void(int)> &f)
     // One set of helper threads for the whole process: the groups of a ChainPool take turns on the
     // host, and two sets of spinning workers would fight for the same cores.  A block of fewer than
     // ~128 chains is not worth a thread.
-    static Workers workers;
+    // The set lives on the heap and is never destroyed; after a fork() (the broker forks chain
+    // processes) the child has none of the parent's threads and starts a set of its own.
+    static Workers *workers = nullptr;
+    static pid_t owner = 0;
     static std::mutex turn;
     std::lock_guard<std::mutex> lk(turn);
-    workers.run(p->nchains, std::max(1, std::min(p->nthreads, p->nchains / 128)), f);
+    if (!workers || owner != getpid()) {
+        workers = new Workers();
+        owner = getpid();
+    }
+    workers->run(p->nchains, std::max(1, std::min(p->nthreads, p->nchains / 128)), f);
 }
 
 // Model.get_vp_vs_h: interfaces midway between neighbouring nuclei, half space h = 0

@@ -172,3 +172,35 @@ def test_result_files_equal_the_reference_chains(oracle, tmp_path):
         cfg = pickle.load(fh)
     assert cfg['targetrefs'] == ['rdispph', 'prf'] and cfg['initparams']['maxmodels'] == 150
     assert np.array_equal(cfg['targets'][0].obsdata.x, pool.targets.targets[0].obsdata.x)
+
+
+def test_helper_threads_survive_a_fork(lib):
+    """The broker forks chain processes; a child of a process that already used the helper threads
+    must get its own (threads do not survive fork) instead of waiting for the parent's."""
+    from chain_scenario import joint_target
+    from bayhunter_amd.chains import ChainPool
+
+    def run():
+        case = CASES['tutorial']
+        rng = np.random.RandomState(0)
+
+        def ev(packed, nlay, noise):
+            return -50 + rng.rand(packed.shape[0]), np.zeros((packed.shape[0], 3))
+        ip = dict(case['initparams'], iter_burnin=12, iter_main=6, acceptance=(40, 100))
+        pool = ChainPool(joint_target(DATA), initparams=ip, modelpriors=case['priors'],
+                         seeds=np.arange(1024) % 1000, evaluator=ev, nthreads=4).run()
+        return int(pool.counters()[0].sum())
+    want = run()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            os.write(w, str(run()).encode())
+        finally:
+            os._exit(0)
+    os.close(w)
+    import select
+    ready, _, _ = select.select([r], [], [], 60)
+    got = os.read(r, 64).decode() if ready else 'timeout'
+    os.waitpid(pid, 0)
+    assert got == str(want) and run() == want
