@@ -20,6 +20,43 @@ int main(int argc, char **argv)
         if (rc != BH_ERR_ARG) { printf("expected BH_ERR_ARG, got %d\n", rc); return 3; }
         printf("arg check ok: %s\n", bh_last_error());
     }
+    {   /* the chain-pool loop from C (host code only): propose -> [likelihoods] -> accept.  The
+         * "likelihood" here is a made-up function of the proposal; real callers run bh_swd_batch /
+         * bh_rf_batch / bh_likelihood_batch on `packed` in between. */
+        enum { NC = 4, LMAX = 8, NM = 64 };
+        static float models[NC * NM * 2 * 6], misfits[NC * NM * 2], likes[NC * NM], noise[NC * NM * 2], vpvs[NC * NM];
+        static double iter[NC * NM], packed[NC * 4 * LMAX], pnoise[NC * 2], logL[NC], mis[NC * 2];
+        int nlay[NC], chain[NC], count = 0, it = 0, i;
+        long nacc[NC];
+        unsigned seeds[NC] = {1, 2, 3, 4};
+        bh_chain_config cfg;
+        bh_chain_storage st;
+        bh_chain_pool *pool = NULL;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.ntargets = 1; cfg.layers_min = 1; cfg.layers_max = 5;
+        cfg.vs_min = 2; cfg.vs_max = 5; cfg.z_min = 0; cfg.z_max = 60;
+        cfg.vpvs_fixed = 0; cfg.vpvs_min = 1.5; cfg.vpvs_max = 2.0;
+        cfg.propdist[0] = .05; cfg.propdist[1] = 1.; cfg.propdist[2] = .1; cfg.propdist[3] = .005; cfg.propdist[4] = .01;
+        cfg.acceptance[0] = 40; cfg.acceptance[1] = 45; cfg.iter_burnin = 30; cfg.iter_main = 30;
+        cfg.noise_fixed[0] = 1; cfg.noise_lo[0] = cfg.noise_hi[0] = 0.;          /* corr fixed at 0    */
+        cfg.noise_fixed[1] = 0; cfg.noise_lo[1] = 1e-5; cfg.noise_hi[1] = 0.05;   /* sigma free        */
+        st.nmodels = NM; st.models = models; st.misfits = misfits; st.likes = likes; st.noise = noise;
+        st.vpvs = vpvs; st.iter = iter;
+        if (bh_chains_create(&cfg, NC, seeds, &st, &pool) != BH_OK) { printf("create: %s\n", bh_last_error()); return 5; }
+        while (!bh_chains_done(pool)) {
+            if (bh_chains_propose(pool, LMAX, packed, nlay, pnoise, chain, &count) != BH_OK) return 6;
+            for (i = 0; i < count; i++) {                /* toy target: 3.5 km/s in the top layer */
+                double d = packed[i * 4 * LMAX + 2 * LMAX] - 3.5;
+                logL[i] = -50. * d * d; mis[2 * i] = mis[2 * i + 1] = d < 0 ? -d : d;
+            }
+            if (bh_chains_accept(pool, logL, mis) != BH_OK) { printf("accept: %s\n", bh_last_error()); return 7; }
+            it++;
+        }
+        if (bh_chains_counters(pool, nacc, NULL, NULL, NULL) != BH_OK) return 8;
+        printf("chains ok: %d rounds, iteration %ld, accepted %ld %ld %ld %ld\n", it, bh_chains_iteration(pool),
+               nacc[0], nacc[1], nacc[2], nacc[3]);
+        bh_chains_destroy(pool);
+    }
     if (argc > 1 && strcmp(argv[1], "run") == 0) {
         /* tutorial model st3 (tutorial/create_testdata.py:13-17), vp = 1.73 vs, rho = .77 + .32 vp */
         float h[4] = {5.f, 23.f, 8.f, 0.f}, vs[4] = {2.7f, 3.6f, 3.8f, 4.4f}, vp[4], rho[4];

@@ -26,6 +26,7 @@ def test_header_is_c99_and_links(lib):
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'bayhunter_amd' in r.stdout and 'arg check ok' in r.stdout
+    assert 'chains ok: 61 rounds, iteration 30' in r.stdout          # initial models + 60 iterations
 
 
 @pytest.mark.gpu
