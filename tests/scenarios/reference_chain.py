@@ -67,6 +67,24 @@ def load_reference():
     return targets, chain.SingleChain
 
 
+def load_plot_from_storage():
+    """-> the reference's PlotFromStorage class (src/Plotting.py, unmodified, loaded file-wise).
+    matplotlib is not installed: empty stand-in modules satisfy the imports (nothing is plotted);
+    `utils.read_config` is the reference's two-line pickle reader (src/utils.py:156-164)."""
+    import pickle
+    T, _ = load_reference()
+    for name in ('matplotlib', 'matplotlib.cm', 'matplotlib.pyplot', 'matplotlib.colors'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    pkg = sys.modules['BayHunter']
+
+    def read_config(configfile):
+        with open(configfile, 'rb') as f:
+            return pickle.load(f)
+    pkg.utils.read_config = read_config
+    pkg.Targets = T
+    return _load('ref_plotting', 'Plotting.py').PlotFromStorage
+
+
 TUTORIAL_PRIORS = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), mohoest=None,
                        rfnoise_corr=0.9, swdnoise_corr=0., rfnoise_sigma=(1e-5, 0.05),
                        swdnoise_sigma=(1e-5, 0.05))

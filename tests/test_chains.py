@@ -204,3 +204,32 @@ def test_helper_threads_survive_a_fork(lib):
     got = os.read(r, 64).decode() if ready else 'timeout'
     os.waitpid(pid, 0)
     assert got == str(want) and run() == want
+
+
+@needs_ref
+def test_reference_plotfromstorage_reads_pool_files(oracle, tmp_path):
+    """the reference's own PlotFromStorage (src/Plotting.py, unmodified) opens a
+    result directory written by ChainPool.save(): finds all chain files, detects outlier chains and
+    merges the main-phase samples into the final distribution files."""
+    case = dict(CASES['fixednoise'])
+    pool = make_pool(oracle, DATA, case, seeds=[5, 6, 7, 8]).run()
+    pool.save(str(tmp_path))
+    data = str(tmp_path / 'data')
+    PlotFromStorage = rc.load_plot_from_storage()
+    obj = PlotFromStorage(os.path.join(data, 'test_config.pkl'))
+    assert obj.ntargets == 2 and obj.refs == ['rdispph', 'prf', 'joint']
+    assert len(obj.likefiles[1]) == 4 and len(obj.modfiles[0]) == 4
+    chains, nmodels = obj._get_chaininfo()
+    # one row per main-phase iteration from the first acceptance of that phase on
+    assert chains == [0, 1, 2, 3] and nmodels == [pool.weighted(i)[2][1].size for i in range(4)]
+    assert all(case['main'] // 2 < n <= case['main'] for n in nmodels)
+    obj.save_final_distribution(maxmodels=200, dev=0.5)
+    likes = np.load(os.path.join(data, 'c_likes.npy'))
+    models = np.load(os.path.join(data, 'c_models.npy'))
+    keep = 4 - len(obj.outliers)
+    mpc = 200 // keep
+    assert keep >= 1 and likes.size == sum(min(n, mpc) for i, n in enumerate(nmodels) if i not in obj.outliers)
+    assert models.shape[0] == likes.size
+    # every merged sample is a stored sample of one of the chains
+    stored = np.concatenate([pool.weighted(i)[2][1] for i in range(4)])
+    assert np.all(np.isin(likes, stored))
