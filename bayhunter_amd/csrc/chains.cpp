@@ -30,7 +30,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <limits>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -196,8 +195,10 @@ public:
             int id = (int)th_.size() + 1;
             th_.emplace_back([this, id]() { loop(id); });
         }
+        // every worker acknowledges every job, also those it has no block in: the job fields below
+        // are never rewritten while a straggler could still be reading them
         f_ = &f; nitems_ = nitems; parts_ = parts;
-        pending_.store(parts - 1);
+        pending_.store((int)th_.size());
         gen_.fetch_add(1);                       // publishes the job (seq_cst)
         { std::lock_guard<std::mutex> lk(m_); }  // a worker about to sleep has either seen it or waits
         start_.notify_all();
@@ -240,11 +241,8 @@ private:
             }
             seen = gen_.load(std::memory_order_acquire);
             if (stop_.load()) return;
-            // a worker may lag one job behind only if it was not part of it, so `parts_` is current
-            if (id < parts_) {
-                block(id);
-                pending_.fetch_sub(1, std::memory_order_release);
-            }
+            if (id < parts_) block(id);
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> th_;

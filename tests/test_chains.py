@@ -233,3 +233,38 @@ def test_reference_plotfromstorage_reads_pool_files(oracle, tmp_path):
     # every merged sample is a stored sample of one of the chains
     stored = np.concatenate([pool.weighted(i)[2][1] for i in range(4)])
     assert np.all(np.isin(likes, stored))
+
+
+def test_threads_and_pool_interleaving_do_not_change_chains(lib):
+    """Chains depend on their seed only: the same chains come out single-threaded, on the helper
+    threads, and when two pools of different size (different thread counts per job) are stepped
+    alternately in one process."""
+    from chain_scenario import joint_target
+    from bayhunter_amd.chains import ChainPool
+    case = CASES['constrained']
+
+    def toy(packed, nlay, noise):                  # deterministic in the proposal, no forward model
+        vs, h = packed[:, 2, :], packed[:, 0, :]
+        d = vs[:, 0] - 3.1 + 0.01 * nlay + 0.002 * h.sum(axis=1)
+        return -40. * d * d - 3. * noise[:, 3], np.stack([np.abs(d), np.abs(d), 2 * np.abs(d)], axis=1)
+
+    def pool(n, nthreads, groups):
+        ip = dict(case['initparams'], iter_burnin=30, iter_main=15, acceptance=(40, 100))
+        return ChainPool(joint_target(DATA), initparams=ip, modelpriors=case['priors'], seeds=(np.arange(n) * 7) % 1000,
+                         evaluator=toy, nthreads=nthreads, groups=groups)
+    ref = pool(1500, 1, 1).run()
+    thr = pool(1500, 8, 2).run()
+    a, b = pool(1500, 8, 1), pool(300, 3, 1)       # stepped alternately: 8-part and 2-part jobs interleave
+    for p in (a, b):
+        p._launch(p.groups[0])
+    while not (a.groups[0].done() and b.groups[0].done()):
+        for p in (a, b):
+            g = p.groups[0]
+            if not g.done():
+                p._land(g)
+                if not g.done():
+                    p._launch(g)
+    for other, n in ((thr, 1500), (a, 1500), (b, 300)):
+        assert np.array_equal(other.counters()[0], ref.counters()[0][:n])
+        for k in ('models', 'likes', 'noise', 'vpvs', 'iter'):
+            assert np.array_equal(getattr(other, k), getattr(ref, k)[:n], equal_nan=True), k
