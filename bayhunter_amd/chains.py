@@ -165,6 +165,10 @@ class ChainPool(object):
                  (packed[B,4,Lmax], nlay[B], noise[B,2*ntargets]) -> (logL[B], misfits[B,ntargets+1])
     groups       number of chain groups alternating between host and GPU (default 2 when the pool
                  has at least 512 chains, else 1)
+    nmodels      rows of sample storage per chain.  Default: the reference's
+                 int(iterations * max(acceptance) / 100) (src/mcmcOptimizer.py:87-89) -- a chain that
+                 accepts more than that overflows (IndexError there, an error from bh_chains_accept
+                 here), which short runs do easily; `iterations + 1` can never overflow.
     shard        (rank, world): this process runs only its contiguous block of the nchains chains
                  (distributed.shard_range), one process per GPU.  Seeds are drawn for ALL chains
                  first, so chain c is the same chain whatever the number of ranks; chains never
@@ -172,7 +176,7 @@ class ChainPool(object):
     """
 
     def __init__(self, targets, initparams=None, modelpriors=None, random_seed=None, nchains=None,
-                 seeds=None, evaluator=None, groups=None, nthreads=None, shard=None):
+                 seeds=None, evaluator=None, groups=None, nthreads=None, shard=None, nmodels=None):
         self.lib = _lib.load()
         self.targets = targets
         self.priors = dict(DEFAULT_PRIORS)
@@ -209,7 +213,8 @@ class ChainPool(object):
         # a fixed correlation is the same number for every chain, a free one selects the exponential law
         targets.set_target_covariance(corrfix, corr, self.initparams['rcond'])
         # the reference's shared arrays (src/mcmcOptimizer.py:77-125)
-        self.nmodels = int(self.iterations * np.max(self.initparams['acceptance']) / 100.)
+        self.nmodels = int(self.iterations * np.max(self.initparams['acceptance']) / 100.) if nmodels is None \
+            else int(nmodels)
         if self.nmodels < 1:
             raise ValueError("iterations * max(acceptance) / 100 leaves no room for accepted models")
         f32 = np.float32

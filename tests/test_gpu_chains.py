@@ -67,3 +67,50 @@ def test_gpu_pool_many_chains_lockstep_and_files(tmp_path):
     assert np.load(str(tmp_path / 'data' / 'c000_p2likes.npy')).shape == (24,)
     for k in ('models', 'likes'):                                   # chain 0 of both pools: same seed
         assert np.array_equal(small.chain(0)[k], pool.chain(0)[k], equal_nan=True)
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from chain_scenario import CASES, joint_target
+    from bayhunter_amd.chains import ChainPool, GpuEvaluator
+    case = CASES['constrained']
+    joint = joint_target(DATA)
+    ip = dict(case['initparams'], iter_burnin=case['burnin'], iter_main=case['main'])
+    pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=[21, 22, 23], shard=(rank, world),
+                     evaluator=GpuEvaluator(joint)).run()
+    full = pool.gather()
+    if rank == 0:
+        q.put({k: v for k, v in full.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gpu_pool_sharded_over_two_ranks(golden_chains):
+    """One process per rank (both on this box's single GPU; the gather runs over gloo, on a node
+    it is RCCL): rank r runs its block of the chains, the gathered blocks are the golden chains."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for i, seed in enumerate((21, 22, 23)):
+        n = int(golden_chains['constrained/%d/n' % seed])
+        assert int(full['naccepted'][i]) == n
+        for k in ('models', 'noise', 'vpvs', 'iter'):
+            assert np.array_equal(full[k][i, :n], golden_chains['constrained/%d/%s' % (seed, k)], equal_nan=True), (seed, k)
+        assert np.allclose(full['likes'][i, :n], golden_chains['constrained/%d/likes' % seed], rtol=3e-7, atol=0)
