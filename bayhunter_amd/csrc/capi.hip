@@ -111,7 +111,7 @@ int g_swd_mode = BH_SWD_AUTO;
 long team_threshold()
 {
     static const char *e = std::getenv("BH_SWD_TEAM_MAX");
-    return e ? std::atol(e) : 12288;   // measured crossover on MI355X
+    return e ? std::atol(e) : 0;       // 0: eight searches per resident wave
 }
 
 int pick_rf_M(int B, int Lmax, int nsamp)
@@ -153,7 +153,7 @@ int bh_set_device(int device)
 
 int bh_swd_set_kernel(int mode)
 {
-    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM16) return fail_arg("unknown kernel mode");
+    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM8) return fail_arg("unknown kernel mode");
     g_swd_mode = mode;
     return BH_OK;
 }
@@ -205,17 +205,45 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
     if (rc) return rc;
     // Few searches: spend a whole wave on each (swd_team.h, ~10x lower latency); many: one lane
     // each (swd_lane, ~5x more searches per second).  bh_swd_set_kernel overrides.
-    // measured on MI355X (profiles/r01_team_widths.txt, 3-15 layers): up to 2048 searches a whole
-    // wave each, up to 4096 half a wave, up to the lane kernel's crossover a quarter
+    // Which kernel: a small cost model fitted to profiles/r01_team_widths.txt (3-15 layers).  A team
+    // kernel with w lanes per search keeps cus * min(8, 160 KiB / LDS per wave) waves resident, 64/w
+    // searches each (`fit`); up to that many searches a call takes one search latency, which is
+    // (relative to the 64-lane team) 1 / 1.7 / 2.9 / 3.4 for w = 64 / 32 / 16 / 8, beyond it grows in
+    // proportion (the teams pull further searches from the queue).  The lane kernel takes 4.6 on that
+    // scale up to its own residency (cus * 8 waves * 64 lanes).  Batches that may hold deep models
+    // (Lmax > 16, measured on ragged 2-31 layers): 1 / 1.9 / 2.1 / 2.4 and 5.4.  BH_SWD_TEAM_MAX
+    // (searches) caps the use of team kernels.
     const long searches = (long)B * ntargets;
-    bool team = searches <= (long)team_threshold();
-    int width = searches <= 2048 ? 64 : searches <= 4096 ? 32 : 16;
+    const long cus = resident > 0 ? resident / 8 : 256;
+    const double lane_fit = (double)(cus * 8 * 64);
+    const bool deep = Lmax > 16;
+    double best = cus > 0 ? (deep ? 5.4 : 4.6) * (searches > lane_fit ? searches / lane_fit : 1.0) : 0.0;
+    bool team = false;
+    int width = 64, team_resident = resident;
+    static const int widths[4] = {64, 32, 16, 8};
+    static const double latency_shallow[4] = {1.0, 1.7, 2.9, 3.4}, latency_deep[4] = {1.0, 1.9, 2.1, 2.4};
+    const double *latency = deep ? latency_deep : latency_shallow;
+    long waves_of[4];
+    for (int i = 0; i < 4; i++) {
+        long per_cu = (long)(160 * 1024 / bh::swd_team_lds_bytes(Lmax, widths[i]));
+        waves_of[i] = cus * (per_cu > 8 ? 8 : per_cu);
+    }
+    if (cus > 0 && (team_threshold() <= 0 || searches <= team_threshold())) {
+        for (int i = 0; i < 4; i++) {
+            const double fit = (double)(waves_of[i] * (64 / widths[i]));
+            if (fit < 1) continue;
+            const double cost = latency[i] * (searches > fit ? searches / fit : 1.0);
+            if (cost < best) { best = cost; team = true; width = widths[i]; team_resident = (int)waves_of[i]; }
+        }
+    }
     if (g_swd_mode == BH_SWD_LANE) team = false;
     if (g_swd_mode >= BH_SWD_TEAM) {
         team = true;
-        width = g_swd_mode == BH_SWD_TEAM16 ? 16 : g_swd_mode == BH_SWD_TEAM32 ? 32 : 64;
+        const int i = g_swd_mode == BH_SWD_TEAM8 ? 3 : g_swd_mode == BH_SWD_TEAM16 ? 2 : g_swd_mode == BH_SWD_TEAM32 ? 1 : 0;
+        width = widths[i];
+        team_resident = waves_of[i] > 0 ? (int)waves_of[i] : 1;
     }
-    if (team) BH_HIP(bh::launch_swd_team(A, width, (hipStream_t)stream));
+    if (team) BH_HIP(bh::launch_swd_team(A, width, team_resident, (hipStream_t)stream));
     else BH_HIP(bh::launch_swd(A, resident, (hipStream_t)stream));
     return BH_OK;
 }

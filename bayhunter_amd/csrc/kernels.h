@@ -73,7 +73,8 @@ struct LikeArgs {
 
 hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream);
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream);
-hipError_t launch_swd_team(const SwdArgs &A, int team_lanes, hipStream_t stream);
+hipError_t launch_swd_team(const SwdArgs &A, int team_lanes, int resident_waves, hipStream_t stream);
+size_t swd_team_lds_bytes(int Lmax, int team_lanes);
 hipError_t launch_rf(const RfArgs &A, hipStream_t stream);
 size_t rf_lds_bytes(int Lmax, int nsamp, int M, bool zr = false);
 

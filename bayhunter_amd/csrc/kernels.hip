@@ -130,10 +130,20 @@ struct TeamSrc {
     const SwdTargetDev &tg;
     int t, lane, nlanes, taken;
     long b;
+    unsigned int *queue;     // nullptr: this team runs search `b` only; else teams pull searches
+                             // from the per-target counter until it runs past the batch
     __device__ __forceinline__ int next(TeamLay &lay, double *&out, double *&cws, double *&cbws)
     {
-        if (taken) return 0;
-        taken = 1;
+        if (queue) {
+            int nb = 0;
+            if (lane == 0) nb = (int)atomicAdd(queue, 1u);
+            nb = __shfl(nb, (int)(threadIdx.x & 63) - lane, 64);      // the team's lane 0
+            if (nb >= A.B) return 0;
+            b = nb;
+        } else {
+            if (taken) return 0;
+            taken = 1;
+        }
         const int L = A.Lmax;
         int nl = A.nlay[b];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
@@ -161,8 +171,10 @@ struct TeamSrc {
 // TEAM lanes per search, 64/TEAM searches per wave (workgroup = one wave).  TEAM = 64 is the lowest
 // latency (most speculation); narrower teams waste fewer lanes in the sequential refinement rounds
 // (1 trial x (L-1) layer matrices) and on shallow models, i.e. more searches per second.  The teams
-// of a wave run the same phases between the barriers; a team whose search is over idles until the
-// last one is done.  (__syncthreads in a one-wave workgroup is an LDS fence, also under divergence.)
+// of a wave run the same phases between the barriers; a team whose search is over pulls the next
+// one from the per-target work queue (so ragged batches do not leave teams idle next to a deep
+// model) and idles only when the queue is empty.  (__syncthreads in a one-wave workgroup is an LDS
+// fence, also under divergence.)
 template <int TEAM>
 __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
 {
@@ -176,8 +188,7 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
     const int per_team = nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * A.Lmax + 1) / 2;
     double *mats = tlds + (long)sub * per_team, *trials = mats + (long)nm * SWD_NCA, *dels = trials + SWD_TEAM_NT;
     TeamLay lay{(float *)(dels + SWD_TEAM_NT), A.Lmax};
-    const long b = (long)blockIdx.x * NSUB + sub;
-    TeamSrc src{A, tg, t, lane, TEAM, (NSUB == 1 || b < A.B) ? 0 : 1, b};
+    TeamSrc src{A, tg, t, lane, TEAM, 0, (long)blockIdx.x, NSUB == 1 ? nullptr : A.counters + t};
     const double *per = A.periods + tg.per_off;
     SwdState S;
     swd_state_init(S);
@@ -229,6 +240,10 @@ __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team16_kernel(SwdArgs A)
 {
     swd_team_body<16>(A);
+}
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team8_kernel(SwdArgs A)
+{
+    swd_team_body<8>(A);
 }
 
 // -------------------------------------------------------------------------------------------- RF
@@ -339,17 +354,34 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
 }
 
 // ---------------------------------------------------------------------------------------- launch
-hipError_t launch_swd_team(const SwdArgs &A, int team, hipStream_t stream)
+// LDS of one wave of the team kernel with `team` lanes per search
+size_t swd_team_lds_bytes(int Lmax, int team)
 {
-    if (team != 16 && team != 32) team = 64;
     const int nsub = SWD_T / team;
-    const int nm = A.Lmax > team ? A.Lmax : team;
-    size_t lds = (size_t)nsub * (nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * A.Lmax + 1) / 2) * sizeof(double);
-    static size_t lds_set[3][16] = {{0}, {0}, {0}};
-    void (*kern)(SwdArgs) = team == 16 ? swd_team16_kernel : team == 32 ? swd_team32_kernel : swd_team_kernel;
-    hipError_t e = ensure_dyn_lds((const void *)kern, lds, lds_set[team == 16 ? 2 : team == 32 ? 1 : 0]);
+    const int nm = Lmax > team ? Lmax : team;
+    return (size_t)nsub * (nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * Lmax + 1) / 2) * sizeof(double);
+}
+
+hipError_t launch_swd_team(const SwdArgs &A, int team, int resident_waves, hipStream_t stream)
+{
+    if (team != 8 && team != 16 && team != 32) team = 64;
+    const int nsub = SWD_T / team;
+    size_t lds = swd_team_lds_bytes(A.Lmax, team);
+    static size_t lds_set[4][16] = {{0}, {0}, {0}, {0}};
+    void (*kern)(SwdArgs) = team == 8 ? swd_team8_kernel : team == 16 ? swd_team16_kernel
+                          : team == 32 ? swd_team32_kernel : swd_team_kernel;
+    hipError_t e = ensure_dyn_lds((const void *)kern, lds, lds_set[team == 8 ? 3 : team == 16 ? 2 : team == 32 ? 1 : 0]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((A.B + nsub - 1) / nsub, A.ntargets), dim3(SWD_T), lds, stream, A);
+    int gx = (A.B + nsub - 1) / nsub;
+    if (nsub > 1) {
+        // persistent waves: no more than stay resident; their teams drain the queue
+        int per_target = resident_waves / A.ntargets;
+        if (per_target < 1) per_target = 1;
+        if (gx > per_target) gx = per_target;
+        e = hipMemsetAsync(A.counters, 0, BH_NT * sizeof(unsigned int), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, A.ntargets), dim3(SWD_T), lds, stream, A);
     return hipGetLastError();
 }
 

@@ -88,14 +88,16 @@ size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets)
 /* Two kernels compute the same values: BH_SWD_LANE gives every lane its own search (throughput:
  * ~6.5e6 searches/s, ~14 ms latency), BH_SWD_TEAM spends a wave per search (speculative bracketing
  * + layer-parallel matrix assembly: ~10x lower latency, ~5x fewer searches/s); TEAM32/TEAM16 put
- * two/four searches on a wave (less speculation, more searches/s).  BH_SWD_AUTO (default) picks by
- * the number of searches in the call: <= 2048 TEAM, <= 4096 TEAM32, <= 12288 TEAM16, else LANE.
+ * 2/4/8 searches on a wave (less speculation, more searches resident and per second).  BH_SWD_AUTO
+ * (default) picks by a fitted cost model on searches per call, Lmax and the device's CU count
+ * (typically: <= 2048 searches TEAM, <= 4096 TEAM32, <= 8192 TEAM16, <= ~22000 TEAM8, else LANE).
  * All of them return identical bits.  Process-wide setting. */
 #define BH_SWD_AUTO 0
 #define BH_SWD_LANE 1
 #define BH_SWD_TEAM 2   /* 64 lanes per search: lowest latency                                     */
 #define BH_SWD_TEAM32 3 /* 32 lanes per search, two searches per wave                               */
-#define BH_SWD_TEAM16 4 /* 16 lanes per search, four per wave: less speculation, ~3x the searches/s */
+#define BH_SWD_TEAM16 4 /* 16 lanes per search, four per wave: less speculation, more searches/s   */
+#define BH_SWD_TEAM8 5  /* 8 lanes per search, eight per wave: layer-parallel assembly only         */
 int bh_swd_set_kernel(int mode);
 int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                  const double *vp, const double *vs, const double *rho, int ntargets,

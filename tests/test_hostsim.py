@@ -38,7 +38,7 @@ def test_swd_team_replay_bitexact(oracle, hostsim, L, srt):
                 n = nl[b]
                 a, e1, n1 = oracle.swd(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], per, iw, ig,
                                        mode, fl, count=True)
-                for nlanes in (64, 32, 16, 7):      # the three kernel widths + an odd one
+                for nlanes in (64, 32, 16, 8, 7):   # the four kernel widths + an odd one
                     r, e2, n2, nspec, nrounds = hostsim.swd_team(H[b, :n], VP[b, :n], VS[b, :n],
                                                                   RHO[b, :n], per, iw, ig, mode, fl, nlanes)
                     assert e1 == e2 and n1 == n2 and nspec >= n2
