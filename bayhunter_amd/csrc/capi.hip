@@ -208,21 +208,22 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
     // Which kernel: a small cost model fitted to profiles/r01_team_widths.txt (3-15 layers).  A team
     // kernel with w lanes per search keeps cus * min(8, 160 KiB / LDS per wave) waves resident, 64/w
     // searches each (`fit`); up to that many searches a call takes one search latency, which is
-    // (relative to the 64-lane team) 1 / 1.7 / 2.9 / 3.4 for w = 64 / 32 / 16 / 8, beyond it grows in
-    // proportion (the teams pull further searches from the queue).  The lane kernel takes 4.6 on that
-    // scale up to its own residency (cus * 8 waves * 64 lanes).  Batches that may hold deep models
-    // (Lmax > 16, measured on ragged 2-31 layers): 1 / 1.9 / 2.1 / 2.4 and 5.4.  BH_SWD_TEAM_MAX
-    // (searches) caps the use of team kernels.
+    // (relative to the 64-lane team, w = 64 / 32 / 16 / 8) 1 / 1.7 / 2.9 / 3.4 around ten layers, where
+    // speculation pays most, 1 / 1.5 / 1.7 / 2.2 for shallow models (Lmax <= 6) and 1 / 1.9 / 2.1 / 2.4
+    // for deep ones (Lmax > 12); beyond `fit` the cost grows in proportion (the teams pull further
+    // searches from the queue).  The lane kernel takes 4.6 (4.2, 5.2) on that scale up to its own
+    // residency (cus * 8 waves * 64 lanes).  BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
     const long searches = (long)B * ntargets;
     const long cus = resident > 0 ? resident / 8 : 256;
     const double lane_fit = (double)(cus * 8 * 64);
-    const bool deep = Lmax > 16;
-    double best = cus > 0 ? (deep ? 5.4 : 4.6) * (searches > lane_fit ? searches / lane_fit : 1.0) : 0.0;
+    const int regime = Lmax <= 6 ? 0 : Lmax <= 12 ? 1 : 2;
+    static const double lane_latency[3] = {4.2, 4.6, 5.2};
+    double best = cus > 0 ? lane_latency[regime] * (searches > lane_fit ? searches / lane_fit : 1.0) : 0.0;
     bool team = false;
     int width = 64, team_resident = resident;
     static const int widths[4] = {64, 32, 16, 8};
-    static const double latency_shallow[4] = {1.0, 1.7, 2.9, 3.4}, latency_deep[4] = {1.0, 1.9, 2.1, 2.4};
-    const double *latency = deep ? latency_deep : latency_shallow;
+    static const double team_latency[3][4] = {{1.0, 1.5, 1.7, 2.2}, {1.0, 1.7, 2.9, 3.4}, {1.0, 1.9, 2.1, 2.4}};
+    const double *latency = team_latency[regime];
     long waves_of[4];
     for (int i = 0; i < 4; i++) {
         long per_cu = (long)(160 * 1024 / bh::swd_team_lds_bytes(Lmax, widths[i]));
