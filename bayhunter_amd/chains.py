@@ -86,7 +86,6 @@ class GpuEvaluator(object):
 
     def submit(self, group, packed, nlay, noise):
         torch = self.torch
-        from .engine import DeviceModels
         B = packed.shape[0]
         if B == 0:
             return None
@@ -95,7 +94,10 @@ class GpuEvaluator(object):
             dp = bufs[0][:B].to(self.device, non_blocking=True)
             dn = bufs[1][:B].to(self.device, non_blocking=True)
             dz = bufs[2][:B].to(self.device, non_blocking=True)
-            logL, misfits = self.joint.evaluate_batch(DeviceModels(dp, dn), noise=dz)
+            # proposals of one iteration have ragged depths: let the engine group them by depth when
+            # the batch is large enough for the lane kernel
+            bt = self.joint._batch or self.joint._build_batch()
+            logL, misfits = self.joint.evaluate_batch(bt['eng'].reorder(dp, dn, ragged=True), noise=dz)
             outs[0][:B].copy_(logL, non_blocking=True)
             outs[1][:B].copy_(misfits, non_blocking=True)
             ev = torch.cuda.Event()

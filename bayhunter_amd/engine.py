@@ -131,10 +131,18 @@ class ForwardEngine(object):
         parts = [self._as_dev(x, f64) for x in (H, VP, VS, RHO)]
         packed = torch.stack(parts, dim=1).contiguous()
         nlay = self._as_dev(nlay, torch.int32)
+        return self.reorder(packed, nlay)
+
+    def reorder(self, packed, nlay, ragged=None):
+        """DeviceModels for a packed [B, 4, Lmax] device tensor; large ragged batches are re-ordered
+        by depth (ForwardEngine.run hands results back in the caller's order).  ragged: True/False
+        when the caller knows (no device round trip), None to look at nlay."""
         inv = None
-        if self.sort_ragged and packed.shape[0] > RAGGED_SORT_MIN:
-            lo, hi = torch.aminmax(nlay)
-            if int(lo) != int(hi):
+        if self.sort_ragged and packed.shape[0] > RAGGED_SORT_MIN and ragged is not False:
+            if ragged is None:
+                lo, hi = torch.aminmax(nlay)
+                ragged = int(lo) != int(hi)
+            if ragged:
                 # lanes of a wave loop over their models' layers in lock step: deepest models first
                 # (similar depths share a wave, and the long searches do not end up as the tail)
                 perm = torch.argsort(nlay, descending=True, stable=True)
