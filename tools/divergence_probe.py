@@ -1,0 +1,32 @@
+"""GPU box: how much of swd_kernel's time is lane divergence?  The same batch size once with random
+models (every lane its own search) and once with one model repeated (all lanes of a wave do exactly
+the same thing: no divergent branches, no waiting for the slowest lane)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bayhunter_amd import _lib
+from bayhunter_amd.engine import ForwardEngine, SwdSpec
+from bayhunter_amd.synthetic import draw_models
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+per = np.linspace(1, 41, 21)
+H, VP, VS, RHO, nl = draw_models(B, 10, seed=1)
+eng = ForwardEngine(swd=[SwdSpec('rdispph', per)])
+_lib.set_swd_kernel('lane')
+def run(tag, *arrs):
+    d = eng.upload(*arrs)
+    out, err = eng.alloc_out(B)
+    eng.run(d, out=out, err=err); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.run(d, out=out, err=err)
+    torch.cuda.synchronize()
+    print('%-28s %8.2f ms' % (tag, (time.perf_counter() - t0) / 3 * 1e3), flush=True)
+run('random models', H, VP, VS, RHO, nl)
+for k in (0, 1, 2):
+    rep = lambda a: np.repeat(a[k:k + 1], B, axis=0)
+    run('model %d repeated' % k, rep(H), rep(VP), rep(VS), rep(RHO), np.repeat(nl[k:k + 1], B))
+# same models, but every wave holds 64 copies of one model (divergence only between waves)
+idx = np.repeat(np.arange(B // 64), 64)
+run('64 copies per wave', H[idx], VP[idx], VS[idx], RHO[idx], nl[idx])
