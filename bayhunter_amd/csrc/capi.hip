@@ -171,6 +171,16 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
                  const bh_swd_target *targets, const double *periods, double *out, int out_stride,
                  int *err, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return bh_swd_batch_ordered(B, Lmax, model_stride, nlay, h, vp, vs, rho, ntargets, targets, periods, out,
+                                out_stride, err, nullptr, workspace, workspace_bytes, stream);
+}
+
+int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, const double *h,
+                         const double *vp, const double *vs, const double *rho, int ntargets,
+                         const bh_swd_target *targets, const double *periods, double *out,
+                         int out_stride, int *err, const int *order, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
     if (model_stride < Lmax) return fail_arg("model_stride < Lmax");
     if (ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("ntargets out of range");
@@ -196,7 +206,7 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
         return BH_ERR_WORKSPACE;
     }
     A.B = B; A.Lmax = Lmax; A.ntargets = ntargets; A.out_stride = out_stride; A.mstride = model_stride;
-    A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.periods = periods;
+    A.nlay = nlay; A.order = order; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.periods = periods;
     A.out = out; A.err = err; A.ws = (double *)workspace;
     A.vec2 = (Lmax % 2 == 0 && model_stride % 2 == 0 &&
               (((uintptr_t)h | (uintptr_t)vp | (uintptr_t)vs | (uintptr_t)rho) & 15) == 0) ? 1 : 0;

@@ -18,6 +18,7 @@ struct SwdArgs {
     int mstride;             // elements between consecutive models in h/vp/vs/rho
     int vec2;                // rows are 16-byte aligned and Lmax is even: fetch two layers per load
     const int *nlay;
+    const int *order;        // optional: the i-th search taken from the queue is model order[i]
     const double *h, *vp, *vs, *rho;
     const double *periods;
     double *out;

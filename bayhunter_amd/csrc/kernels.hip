@@ -63,6 +63,7 @@ struct QueueSrc {
     {
         unsigned int b = atomicAdd(counter, 1u);
         if (b >= (unsigned int)A.B) return 0;
+        if (A.order) b = (unsigned int)A.order[b];
         cur = b;
         const int L = A.Lmax;
         int nl = A.nlay[b];
@@ -139,10 +140,11 @@ struct TeamSrc {
             if (lane == 0) nb = (int)atomicAdd(queue, 1u);
             nb = __shfl(nb, (int)(threadIdx.x & 63) - lane, 64);      // the team's lane 0
             if (nb >= A.B) return 0;
-            b = nb;
+            b = A.order ? A.order[nb] : nb;
         } else {
             if (taken) return 0;
             taken = 1;
+            if (A.order) b = A.order[b];
         }
         const int L = A.Lmax;
         int nl = A.nlay[b];

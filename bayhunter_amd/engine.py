@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-RAGGED_SORT_MIN = 8192   # below this the team kernel runs (one wave per model): order is irrelevant
+ORDER_MIN = 8192         # below this one wave works on one search (64/32-lane teams): order is irrelevant
 
 SWD_REFS = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
 RF_REFS = {'prf': 0, 'seis': 0, 'srf': 1}
@@ -32,14 +32,14 @@ class DeviceModels(object):
     """A batch of layered models resident in HBM: `packed` is [B, 4, Lmax] fp64 (h, vp, vs, rho
     rows of each model contiguous, zero padded), `nlay` int32 [B].  H/VP/VS/RHO are views."""
 
-    def __init__(self, packed, nlay, inv=None):
+    def __init__(self, packed, nlay, order=None):
         assert packed.dim() == 3 and packed.shape[1] == 4 and packed.is_contiguous()
         self.packed, self.nlay = packed, nlay
         self.B, self.Lmax = packed.shape[0], packed.shape[2]
         self.H, self.VP, self.VS, self.RHO = (packed[:, i, :] for i in range(4))
-        # When the batch was re-ordered at upload (ragged layer counts), row i of the caller's arrays
-        # sits at row inv[i] here; ForwardEngine.run hands results back in the caller's order.
-        self.inv = inv
+        # Processing order of the dispersion searches (int32 permutation, ForwardEngine.reorder):
+        # the data stay where they are and results land in the caller's rows.
+        self.order = order
 
 
 class SwdSpec(object):
@@ -134,22 +134,21 @@ class ForwardEngine(object):
         return self.reorder(packed, nlay)
 
     def reorder(self, packed, nlay, ragged=None):
-        """DeviceModels for a packed [B, 4, Lmax] device tensor; large ragged batches are re-ordered
-        by depth (ForwardEngine.run hands results back in the caller's order).  ragged: True/False
-        when the caller knows (no device round trip), None to look at nlay."""
-        inv = None
-        if self.sort_ragged and packed.shape[0] > RAGGED_SORT_MIN and ragged is not False:
-            if ragged is None:
-                lo, hi = torch.aminmax(nlay)
-                ragged = int(lo) != int(hi)
-            if ragged:
-                # lanes of a wave loop over their models' layers in lock step: deepest models first
-                # (similar depths share a wave, and the long searches do not end up as the tail)
-                perm = torch.argsort(nlay, descending=True, stable=True)
-                packed, nlay = packed[perm].contiguous(), nlay[perm].contiguous()
-                inv = torch.empty_like(perm)
-                inv[perm] = torch.arange(perm.numel(), device=perm.device)
-        return DeviceModels(packed, nlay, inv)
+        """DeviceModels for a packed [B, 4, Lmax] device tensor, with a processing order for large
+        batches: the lanes of a wave (and the teams sharing one) run their searches in lock step, so
+        neighbours should be alike.  Deepest models first (the layer loop runs to the deepest model
+        of a wave, and long searches should not form the tail), and within one depth by the S-wave
+        travel time through the stack, a cheap predictor of where the dispersion curve lies and how
+        long its search takes: 10 % at 524 288 ten-layer models (profiles/r01_divergence_probe.txt).
+        No data move; bh_swd_batch_ordered takes the permutation.  (`ragged` is accepted for
+        compatibility: the order is computed without a device round trip either way.)"""
+        order = None
+        if self.sort_ragged and self.swd and packed.shape[0] > ORDER_MIN:
+            H, VS = packed[:, 0, :], packed[:, 2, :]
+            tt = torch.where(VS > 0, H / VS.clamp_min(1e-300), torch.zeros_like(H)).sum(dim=1)
+            order = torch.argsort(tt)
+            order = order[torch.argsort(nlay[order], descending=True, stable=True)].to(torch.int32)
+        return DeviceModels(packed, nlay, order)
 
     def alloc_out(self, B):
         out = torch.empty((B, self.row), dtype=torch.float64, device=self.device)
@@ -166,8 +165,7 @@ class ForwardEngine(object):
         H, VP, VS, RHO, nlay = models.H, models.VP, models.VS, models.RHO, models.nlay
         B, Lmax = models.B, models.Lmax
         mstride = 4 * Lmax
-        user_out, user_err = out, err
-        if out is None or err is None or models.inv is not None:
+        if out is None or err is None:
             out, err = self.alloc_out(B)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         sp = C.c_void_p(st.cuda_stream)
@@ -190,10 +188,11 @@ class ForwardEngine(object):
                         ws = self._ws[st.cuda_stream] = torch.empty((need + 7) // 8, dtype=torch.float64,
                                                                     device=self.device)
                     ws_ptr = ws.data_ptr()
-                _lib.check(self.lib.bh_swd_batch(
+                _lib.check(self.lib.bh_swd_batch_ordered(
                     B, Lmax, mstride, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
                     RHO.data_ptr(), len(self.swd), self._tg, self.periods.data_ptr(),
-                    out.data_ptr(), self.row, err.data_ptr(), ws_ptr, need, sp))
+                    out.data_ptr(), self.row, err.data_ptr(),
+                    models.order.data_ptr() if models.order is not None else None, ws_ptr, need, sp))
             else:
                 err.zero_()
             rsp = sp if side is None else C.c_void_p(side.cuda_stream)
@@ -205,11 +204,4 @@ class ForwardEngine(object):
                 st.wait_stream(side)
                 for t in (H, VP, VS, RHO, nlay, out):
                     t.record_stream(side)
-            if models.inv is not None:       # back to the caller's row order
-                if user_out is not None and user_err is not None:
-                    torch.index_select(out, 0, models.inv, out=user_out)
-                    torch.index_select(err, 0, models.inv, out=user_err)
-                    out, err = user_out, user_err
-                else:
-                    out, err = out.index_select(0, models.inv), err.index_select(0, models.inv)
         return out, err

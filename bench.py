@@ -233,7 +233,9 @@ def main():
     out, err = eng_swd.alloc_out(B)
 
     def step():
-        eng_swd.run(dmodels, out=out, err=err)
+        # a sampler brings new models every step: the processing order (a sort by depth and S travel
+        # time, engine.reorder) is part of the step, not of the upload
+        eng_swd.run(eng_swd.reorder(dmodels.packed, dmodels.nlay), out=out, err=err)
 
     for _ in range(args.warmup):
         step()

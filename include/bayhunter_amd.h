@@ -104,6 +104,16 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
                  const bh_swd_target *targets,
                  const double *periods, double *out, int out_stride, int *err,
                  void *workspace, size_t workspace_bytes, void *stream);
+/* Same, with a processing order: order[i] (device, int[B], a permutation of 0..B-1) is the model
+ * the i-th search slot works on; results still land in row order[i].  The lanes of a wave run in
+ * lock step, so putting models of similar depth and similar search length next to each other
+ * saves 10 % at half a million models (bayhunter_amd/engine.py orders by layer count, then by the
+ * S-wave travel time through the stack).  order == NULL is bh_swd_batch. */
+int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, const double *h,
+                         const double *vp, const double *vs, const double *rho, int ntargets,
+                         const bh_swd_target *targets, const double *periods, double *out,
+                         int out_stride, int *err, const int *order, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* ---- batched receiver functions (device pointers) --------------------------------------- */
 /* qp/qs may be NULL: 500 / 225 like rfmini_modrf.py:119-120.  Output: the first nout samples of

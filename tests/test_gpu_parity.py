@@ -396,15 +396,18 @@ def test_synrf_dropin_returns_all_three_traces(lib, oracle):
 
 
 def test_ragged_batch_is_reordered_transparently(lib, oracle):
-    """Above 8192 models a ragged batch is sorted by layer count at upload; results come back in the
-    caller's order, identical to the unsorted run, with and without caller-provided buffers."""
+    """Above 8192 models the searches are processed deepest first and by S travel time within a
+    depth (a permutation handed to bh_swd_batch_ordered); results land in the caller's rows,
+    identical to the unordered run, with and without caller-provided buffers, lane and team kernels."""
     import torch
     from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
     H, VP, VS, RHO, nl = draw_models(9000, (2, 12), seed=41, sorted_vs=False)
     per = np.linspace(1, 41, 11)
     eng = ForwardEngine(swd=[SwdSpec('rdispph', per)], rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
     models = eng.upload(H, VP, VS, RHO, nl)
-    assert models.inv is not None
+    order = models.order.cpu().numpy()
+    assert order.dtype == np.int32 and np.array_equal(np.sort(order), np.arange(9000))
+    assert np.all(np.diff(nl[order]) <= 0)                       # deepest first
     out, err = eng.run(models)
     buf_out, buf_err = eng.alloc_out(9000)
     eng.run(models, out=buf_out, err=buf_err)
@@ -413,6 +416,15 @@ def test_ragged_batch_is_reordered_transparently(lib, oracle):
     torch.cuda.synchronize()
     for o, e in ((out, err), (buf_out, buf_err)):
         assert torch.equal(o.nan_to_num(nan=-1.0), ref_out.nan_to_num(nan=-1.0)) and torch.equal(e, ref_err)
+    from bayhunter_amd import _lib
+    for mode in ('lane', 'team16', 'team8'):
+        _lib.set_swd_kernel(mode)
+        try:
+            o, e = eng.run(models)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_swd_kernel('auto')
+        assert torch.equal(o.nan_to_num(nan=-1.0), ref_out.nan_to_num(nan=-1.0)) and torch.equal(e, ref_err), mode
     sl = slice(100, 132)
     want, werr, _ = oracle.swd_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl], per, 2, 0)
     assert np.array_equal(err.cpu().numpy()[sl, 0], werr)

@@ -30,3 +30,20 @@ for k in (0, 1, 2):
 # same models, but every wave holds 64 copies of one model (divergence only between waves)
 idx = np.repeat(np.arange(B // 64), 64)
 run('64 copies per wave', H[idx], VP[idx], VS[idx], RHO[idx], nl[idx])
+# do lanes with similar models diverge less?  order the batch by a scalar (or two) of the model
+Z = np.cumsum(H, axis=1)
+tt = (H[:, :-1] / VS[:, :-1]).sum(axis=1)
+def vs_at(depth):
+    i = np.minimum((Z[:, :-1] < depth).sum(axis=1), nl - 1)
+    return VS[np.arange(B), i]
+def bins(x, n):
+    return np.digitize(x, np.quantile(x, np.linspace(0, 1, n + 1)[1:-1]))
+keys = {
+    'S travel time': (tt,),
+    'travel time in 32 bins, then vs[0]': (VS[:, 0], bins(tt, 32)),
+    'P+S travel time': ((H[:, :-1] / VS[:, :-1]).sum(axis=1) + (H[:, :-1] / VP[:, :-1]).sum(axis=1),),
+    'travel time to 20 km': ((np.minimum(Z[:, :-1], 20.) - np.minimum(Z[:, :-1] - H[:, :-1], 20.)).clip(0) .__truediv__(VS[:, :-1]).sum(axis=1),),
+}
+for tag, ks in keys.items():
+    o = np.lexsort(ks)
+    run('sorted: ' + tag, H[o], VP[o], VS[o], RHO[o], nl[o])
