@@ -146,8 +146,9 @@ class ForwardEngine(object):
         if self.sort_ragged and self.swd and packed.shape[0] > ORDER_MIN:
             H, VS = packed[:, 0, :], packed[:, 2, :]
             tt = torch.where(VS > 0, H / VS.clamp_min(1e-300), torch.zeros_like(H)).sum(dim=1)
-            order = torch.argsort(tt)
-            order = order[torch.argsort(nlay[order], descending=True, stable=True)].to(torch.int32)
+            # one sort: depth (descending) is the major key, travel time (< 1e4 s) the minor one
+            key = (tt.clamp(0., 9.9e3) - nlay.to(torch.float64) * 1.0e4).to(torch.float32)
+            order = torch.argsort(key).to(torch.int32)
         return DeviceModels(packed, nlay, order)
 
     def alloc_out(self, B):
