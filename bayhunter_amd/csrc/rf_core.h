@@ -59,15 +59,15 @@ BH_HD RfLayout rf_layout(int Lmax, int nsamp)
     RfLayout lo;
     int nfreq = nsamp / 2 + 1;
     lo.L = Lmax;
-    lo.off_par = 2 * nfreq;            // [6][L]: d, vp, vs, rho, qp, qs (flattened model)
-    lo.off_coef = lo.off_par + 6 * Lmax; // [L][32]: rd, td, ru, tu of interface i (above layer i)
+    lo.off_par = 2 * nfreq;            // [8][L]: d, vp, vs, rho, 1/(pi qp), 1/(pi qs), 1/vp^2, 1/vs^2
+    lo.off_coef = lo.off_par + 8 * Lmax; // [L][32]: rd, td, ru, tu of interface i (above layer i)
     lo.off_sc = lo.off_coef + 32 * Lmax; // 16 scalars
     int need = lo.off_sc + 16;
     lo.per_model = need > 2 * nsamp ? need : 2 * nsamp;
     return lo;
 }
 enum { RF_SC_H2 = 0, RF_SC_T0 = 8, RF_SC_M11 = 9, RF_SC_M12 = 10, RF_SC_M21 = 11, RF_SC_M22 = 12,
-       RF_SC_DECOMP = 13 };
+       RF_SC_DECOMP = 13, RF_SC_UNIFORM_Q = 14 };
 
 BH_DEV void st_cd(double *p, cd v) { p[0] = v.re; p[1] = v.im; }
 BH_DEV cd ld_cd(const double *p) { return mk(p[0], p[1]); }
@@ -122,8 +122,12 @@ BH_DEV void rf_phase1_layer(double *S, const RfLayout &lo, int nlay, int i, cons
     par[1 * lo.L + i] = lvp;
     par[2 * lo.L + i] = lvs;
     par[3 * lo.L + i] = lrh;
-    par[4 * lo.L + i] = qp ? qp[i] : 500.0;      // rfmini_modrf.py:119-120
-    par[5 * lo.L + i] = qs ? qs[i] : 225.0;
+    // Q enters every frequency only through 1/(pi Q) and 1/(2 Q) = (pi/2) / (pi Q) (Mueller 1985
+    // eq. 132, greens.cpp:539-540): keep the reciprocal, and 1/v^2 for the shared-Q form of phase 3
+    par[4 * lo.L + i] = frcp(BH_PI * (qp ? qp[i] : 500.0));      // rfmini_modrf.py:119-120
+    par[5 * lo.L + i] = frcp(BH_PI * (qs ? qs[i] : 225.0));
+    par[6 * lo.L + i] = frcp(lvp * lvp);
+    par[7 * lo.L + i] = frcp(lvs * lvs);
 }
 
 // ---- P2: interface coefficients ---------------------------------------------------------------------
@@ -225,6 +229,12 @@ BH_DEV void rf_phase2_interface(double *S, const RfLayout &lo, const RfLaunch &P
         const double *v = par + (P.waveno == 0 ? 1 : 2) * lo.L;
         for (int k = 0; k < nlay; k++) t0 += par[k] * sqrt(1. / (v[k] * v[k]) - P.p2);
         sc[RF_SC_T0] = t0;
+        // one Q for all layers (what BayHunter passes): the complex velocity factor is then the same
+        // for every layer of a frequency
+        bool uniform = true;
+        for (int k = 1; k < nlay - 1; k++)
+            uniform = uniform && par[4 * lo.L + k] == par[4 * lo.L] && par[5 * lo.L + k] == par[5 * lo.L];
+        sc[RF_SC_UNIFORM_Q] = uniform ? 1.0 : 0.0;
         // rotation velocities: wrap.cpp:13,73-74 with rfmini_modrf.py:125-130
         double sigma = P.sigma;
         if (!(sigma == sigma)) {
@@ -261,14 +271,27 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
     const double w = P.dw * j;
     const double lgw = j ? log(w / P.wref) : 0;
     cm2 nb = cm2_zero(), q = cm2_zero(), g = cm2_zero();
+    // complex velocity v (1 + ln(w/wref)/(pi Q) + i/(2 Q)), Mueller (1985) eq. 132: 1/v_c^2 =
+    // (1/v^2) * 1/f^2 with f the bracket; with one Q for all layers f is a per-frequency constant
+    const bool uniform = sc[RF_SC_UNIFORM_Q] != 0.0;
+    cd gp, gs;
+    {
+        const double ap = par[4 * lo.L], as = par[5 * lo.L];
+        cd fp = mk(1. + lgw * ap, ap * (0.5 * BH_PI)), fs = mk(1. + lgw * as, as * (0.5 * BH_PI));
+        gp = crecip(fp * fp);
+        gs = crecip(fs * fs);
+    }
     for (int i = 0; i < nlay - 1; i++) {        // reference layer index i+1 = 1 .. nlay-1
-        double d = par[i], vp = par[lo.L + i], vs = par[2 * lo.L + i], qp = par[4 * lo.L + i],
-               qs = par[5 * lo.L + i];
+        const double d = par[i];
         cd miwd = mk(0., -w * d);
-        cd vpc = mk(1. + lgw * frcp(BH_PI * qp), frcp(2. * qp)) * vp;   // Mueller (1985) eq. 132
-        cd vsc = mk(1. + lgw * frcp(BH_PI * qs), frcp(2. * qs)) * vs;
-        cd plc = csqrt_fast(crecip(vpc * vpc) - P.p2);               // Q finite -> im != 0
-        cd slc = csqrt_fast(crecip(vsc * vsc) - P.p2);
+        if (!uniform && i > 0) {                // this layer has its own Q
+            const double ap = par[4 * lo.L + i], as = par[5 * lo.L + i];
+            cd fp = mk(1. + lgw * ap, ap * (0.5 * BH_PI)), fs = mk(1. + lgw * as, as * (0.5 * BH_PI));
+            gp = crecip(fp * fp);
+            gs = crecip(fs * fs);
+        }
+        cd plc = csqrt_fast(gp * par[6 * lo.L + i] - P.p2);         // Q finite -> im != 0
+        cd slc = csqrt_fast(gs * par[7 * lo.L + i] - P.p2);
         cd e11 = cexp_(miwd * plc), e22 = cexp_(miwd * slc);
         const double *ci = coef + 32 * i, *cn = coef + 32 * (i + 1);
         cm2 nt;

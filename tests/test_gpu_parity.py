@@ -372,7 +372,9 @@ def test_division_selftest(lib):
 
 
 def test_synrf_dropin_returns_all_three_traces(lib, oracle):
-    """bh_synrf with fz/fr buffers = the full return value of rfmini.synrf (fz, fr, rf), P and SV."""
+    """bh_synrf with fz/fr buffers = the full return value of rfmini.synrf (fz, fr, rf), P and SV;
+    one Q for all layers (models 0, 1: the shared-factor form of the recursion) and Q varying
+    from layer to layer (models 2, 3: the general form)."""
     from bayhunter_amd import _lib
     H, VP, VS, RHO, nl = draw_models(4, (3, 9), seed=17, sorted_vs=False)
     for b in range(4):
@@ -380,6 +382,8 @@ def test_synrf_dropin_returns_all_three_traces(lib, oracle):
         z = np.ascontiguousarray(np.concatenate(([0], np.cumsum(H[b, :n])[:-1])))
         vp, vs, rh = (np.ascontiguousarray(a[b, :n]) for a in (VP, VS, RHO))
         qp, qs = np.full(n, 450.), np.full(n, 200.)
+        if b >= 2:
+            qp, qs = qp + 35. * np.arange(n), qs - 12. * np.arange(n)
         for wn, nsamp in ((0, 512), (1, 256)):
             want = oracle.synrf(z, vp, vs, rh, qp, qs, 6.4, 1.5, nsamp, 5.0, 5.0, 3.1, 0.27, wn)
             fz, fr, rf = np.zeros(nsamp), np.zeros(nsamp), np.zeros(nsamp)
