@@ -38,7 +38,7 @@ def main():
         seeds = [case['seed'], case['seed'] + 1, case['seed'] + 2]
         out['%s/seeds' % name] = np.array(seeds)
         for seed in seeds:
-            res = rc.run_chain(lambda xs, xr: (OraclePlugin(oracle, xs, 'swd'), OraclePlugin(oracle, xr, 'rf')),
+            res = rc.run_chain(None, refs=case.get('refs', ('rdispph', 'prf')), plugin_for=lambda ref, x: OraclePlugin(oracle, x, ref),
                                seed=seed, burnin=case['burnin'], main=case['main'], data_dir=data,
                                priors=case['priors'], initparams=case['initparams'])
             print(name, seed, 'accepted', res['n'], 'propdist', res['propdist'])

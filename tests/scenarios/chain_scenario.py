@@ -30,36 +30,65 @@ CASES = {
                        initparams=dict(propdist=(0.03, 0.8, 0.1, 0.005, 0.01), acceptance=(30, 60),
                                        thickmin=0.1, lvz=None, hvz=None, rcond=None, station='test',
                                        savepath='results', maxmodels=50000)),
+    # all six data sets of the tutorial station: exponential covariance for the four dispersion
+    # targets (fixed correlation) and for the two receiver functions (free correlation)
+    'sixtargets': dict(seed=33, burnin=260, main=140, refs=('rdispph', 'rdispgr', 'ldispph', 'ldispgr', 'prf', 'srf'),
+                       priors=dict(vpvs=(1.5, 2.0), layers=(1, 10), vs=(2, 5), z=(0, 60), mohoest=None,
+                                   rfnoise_corr=(0.8, 0.98), swdnoise_corr=0.25,
+                                   rfnoise_sigma=(1e-5, 0.05), swdnoise_sigma=(1e-5, 0.1)),
+                       initparams=dict(propdist=(0.02, 0.4, 0.05, 0.005, 0.01), acceptance=(40, 70),
+                                       thickmin=0.2, lvz=None, hvz=None, rcond=None, station='test',
+                                       savepath='results', maxmodels=50000)),
 }
 
 
+REFS = {'rdispph': ('swd', 2, 0), 'rdispgr': ('swd', 2, 1), 'ldispph': ('swd', 1, 0), 'ldispgr': ('swd', 1, 1),
+        'prf': ('rf', 0), 'srf': ('rf', 1)}
+TWO = ('rdispph', 'prf')
+
+
 class OraclePlugin(object):
-    """The forward-plugin contract on top of the CPU oracle."""
+    """The forward-plugin contract on top of the CPU oracle.  kind: 'swd' (Rayleigh phase), 'rf'
+    (P receiver function) or a target ref of REFS."""
 
     def __init__(self, oracle, x, kind):
-        self.oracle, self.obsx, self.kind = oracle, x, kind
+        self.oracle, self.obsx = oracle, x
+        spec = REFS.get(kind, ('swd', 2, 0) if kind == 'swd' else ('rf', 0))
+        self.kind, self.args = spec[0], spec[1:]
 
     def __getstate__(self):
-        return dict(obsx=self.obsx, kind=self.kind, oracle=None)      # a module does not pickle
+        return dict(obsx=self.obsx, kind=self.kind, args=self.args, oracle=None)   # a module does not pickle
 
     def run_model(self, h, vp, vs, rho, **kw):
         if self.kind == 'swd':
-            y, err = self.oracle.swd(h, vp, vs, rho, self.obsx, 2, 0)
+            y, err = self.oracle.swd(h, vp, vs, rho, self.obsx, self.args[0], self.args[1])
             return (self.obsx, y) if err == 0 else (np.nan, np.nan)
-        return self.obsx, self.oracle.rf_model(h, vp, vs, rho, nout=self.obsx.size)
+        return self.obsx, self.oracle.rf_model(h, vp, vs, rho, nout=self.obsx.size, waveno=self.args[0])
 
 
-def joint_target(data_dir, plugins=None):
+def target_classes(T):
+    return {'rdispph': T.RayleighDispersionPhase, 'rdispgr': T.RayleighDispersionGroup,
+            'ldispph': T.LoveDispersionPhase, 'ldispgr': T.LoveDispersionGroup,
+            'prf': T.PReceiverFunction, 'srf': T.SReceiverFunction}
+
+
+def joint_target(data_dir, plugins=None, refs=TWO, oracle=None):
+    """JointTarget on the tutorial's observed data.  plugins(xsw, xrf) -> two plugins (the two-target
+    set-ups), or oracle: an OraclePlugin per ref; neither: the package's own GPU plugins."""
     from bayhunter_amd import targets as T
-    sw = np.loadtxt(os.path.join(data_dir, 'st3_rdispph.dat'))
-    rf = np.loadtxt(os.path.join(data_dir, 'st3_prf.dat'))
-    t1 = T.RayleighDispersionPhase(sw[:, 0], sw[:, 1])
-    t2 = T.PReceiverFunction(rf[:, 0], rf[:, 1])
+    cls = target_classes(T)
+    out = []
+    for ref in refs:
+        d = np.loadtxt(os.path.join(data_dir, 'st3_%s.dat' % ref))
+        out.append(cls[ref](d[:, 0], d[:, 1]))
     if plugins is not None:
-        p1, p2 = plugins(sw[:, 0], rf[:, 0])
-        t1.update_plugin(p1)
-        t2.update_plugin(p2)
-    return T.JointTarget([t1, t2])
+        p1, p2 = plugins(out[0].obsdata.x, out[1].obsdata.x)
+        out[0].update_plugin(p1)
+        out[1].update_plugin(p2)
+    elif oracle is not None:
+        for ref, t in zip(refs, out):
+            t.update_plugin(OraclePlugin(oracle, t.obsdata.x, ref))
+    return T.JointTarget(out)
 
 
 def oracle_evaluator(joint):
@@ -78,11 +107,12 @@ def oracle_evaluator(joint):
 
 def make_pool(oracle, data_dir, case, seeds, groups=None, evaluator=None):
     from bayhunter_amd.chains import ChainPool
+    refs = case.get('refs', TWO)
     if evaluator is None:
-        joint = joint_target(data_dir, lambda xs, xr: (OraclePlugin(oracle, xs, 'swd'), OraclePlugin(oracle, xr, 'rf')))
+        joint = joint_target(data_dir, refs=refs, oracle=oracle)
         evaluator = oracle_evaluator(joint)
     else:
-        joint = joint_target(data_dir)
+        joint = joint_target(data_dir, refs=refs)
         evaluator = evaluator(joint)
     ip = dict(case['initparams'], iter_burnin=case['burnin'], iter_main=case['main'])
     return ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=seeds, evaluator=evaluator,

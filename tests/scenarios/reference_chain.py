@@ -94,19 +94,26 @@ TUTORIAL_INITPARAMS = dict(nchains=1, propdist=(0.015, 0.015, 0.015, 0.005, 0.00
 
 
 def run_chain(make_plugins, seed=7, burnin=120, main=60, data_dir=None, priors=None, initparams=None,
-              savepath=None):
+              savepath=None, refs=('rdispph', 'prf'), plugin_for=None):
     """Build the tutorial's joint target (Rayleigh phase + P-RF), install the plugins returned by
     make_plugins(xsw, xrf) with the reference's update_plugin hook, run one reference chain.
     With `savepath` the chain also writes its result files (SingleChain.save_finalmodels)."""
     T, SingleChain = load_reference()
-    sw = np.loadtxt(os.path.join(data_dir, 'st3_rdispph.dat'))
-    rf = np.loadtxt(os.path.join(data_dir, 'st3_prf.dat'))
-    t1 = T.RayleighDispersionPhase(sw[:, 0], sw[:, 1])
-    t2 = T.PReceiverFunction(rf[:, 0], rf[:, 1])
-    p1, p2 = make_plugins(sw[:, 0], rf[:, 0])
-    t1.update_plugin(p1)
-    t2.update_plugin(p2)
-    joint = T.JointTarget(targets=[t1, t2])
+    cls = {'rdispph': T.RayleighDispersionPhase, 'rdispgr': T.RayleighDispersionGroup,
+           'ldispph': T.LoveDispersionPhase, 'ldispgr': T.LoveDispersionGroup,
+           'prf': T.PReceiverFunction, 'srf': T.SReceiverFunction}
+    tl = []
+    for ref in refs:
+        d = np.loadtxt(os.path.join(data_dir, 'st3_%s.dat' % ref))
+        tl.append(cls[ref](d[:, 0], d[:, 1]))
+    if plugin_for is not None:                     # plugin_for(ref, x) -> plugin, any number of targets
+        for ref, t in zip(refs, tl):
+            t.update_plugin(plugin_for(ref, t.obsdata.x))
+    else:
+        p1, p2 = make_plugins(tl[0].obsdata.x, tl[1].obsdata.x)
+        tl[0].update_plugin(p1)
+        tl[1].update_plugin(p2)
+    joint = T.JointTarget(targets=tl)
     pr = dict(TUTORIAL_PRIORS)
     pr.update(priors or {})
     ip = dict(TUTORIAL_INITPARAMS, iter_burnin=burnin, iter_main=main)
@@ -118,9 +125,9 @@ def run_chain(make_plugins, seed=7, burnin=120, main=60, data_dir=None, priors=N
     maxlayers = int(pr['layers'][1]) + 1
     f32 = np.float32
     shared = dict(sharedmodels=np.full(nmodels * maxlayers * 2, np.nan, dtype=f32),
-                  sharedmisfits=np.full(nmodels * 3, np.nan, dtype=f32),
+                  sharedmisfits=np.full(nmodels * (len(refs) + 1), np.nan, dtype=f32),
                   sharedlikes=np.full(nmodels, np.nan, dtype=f32),
-                  sharednoise=np.full(nmodels * 4, np.nan, dtype=f32),
+                  sharednoise=np.full(nmodels * 2 * len(refs), np.nan, dtype=f32),
                   sharedvpvs=np.full(nmodels, np.nan, dtype=f32))
     chain = SingleChain(targets=joint, chainidx=0, initparams=ip, modelpriors=pr,
                         random_seed=seed, **shared)

@@ -114,7 +114,7 @@ def _same(ref, got, name):
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_pool_chain_is_the_reference_chain(oracle, name):
     case = CASES[name]
-    ref = rc.run_chain(lambda xs, xr: (OraclePlugin(oracle, xs, 'swd'), OraclePlugin(oracle, xr, 'rf')),
+    ref = rc.run_chain(None, refs=case.get('refs', ('rdispph', 'prf')), plugin_for=lambda ref, x: OraclePlugin(oracle, x, ref),
                        seed=case['seed'], burnin=case['burnin'], main=case['main'], data_dir=DATA,
                        priors=case['priors'], initparams=case['initparams'])
     pool = make_pool(oracle, DATA, case, seeds=[case['seed']]).run()
@@ -156,7 +156,7 @@ def test_storage_overflow_is_reported(oracle):
 def test_result_files_equal_the_reference_chains(oracle, tmp_path):
     case = CASES['tutorial']
     refdir, mydir = str(tmp_path / 'ref'), str(tmp_path / 'mine')
-    rc.run_chain(lambda xs, xr: (OraclePlugin(oracle, xs, 'swd'), OraclePlugin(oracle, xr, 'rf')),
+    rc.run_chain(None, refs=case.get('refs', ('rdispph', 'prf')), plugin_for=lambda ref, x: OraclePlugin(oracle, x, ref),
                  seed=case['seed'], burnin=case['burnin'], main=case['main'], data_dir=DATA,
                  priors=case['priors'], initparams=dict(case['initparams'], maxmodels=150), savepath=refdir)
     case = dict(case, initparams=dict(case['initparams'], maxmodels=150))
