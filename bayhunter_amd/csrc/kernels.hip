@@ -307,9 +307,9 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     }
     __syncthreads();
     // P3: (model, frequency) tasks, model-major
-    const int ntask = Mb * P.nfreq;
+    const int ntask = Mb * P.nact;
     for (int task = tid; task < ntask; task += RF_T) {
-        int m = task / P.nfreq, j = task - m * P.nfreq;
+        int m = task / P.nact, j = task - m * P.nact;
         int nl = A.nlay[b0 + m];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         double *Sm = S + (long)m * pm;
@@ -322,6 +322,17 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         } else {
             cd crf = rf_phase3_task(Sm, lo, P, nl, j);
             st_cd(Sm + 2 * j, crf);
+        }
+    }
+    // frequencies whose filter weight is below 1e-24 (rf_host.h): zero
+    const int nzero = P.nfreq - P.nact;
+    for (int idx = tid; idx < Mb * nzero; idx += RF_T) {
+        int m = idx / nzero, j = P.nact + (idx - m * nzero);
+        double *Sm = S + (long)m * pm;
+        st_cd(Sm + 2 * j, mk(0., 0.));
+        if (ZR) {
+            st_cd(Sm + lo.per_model + 2 * j, mk(0., 0.));
+            st_cd(Sm + lo.per_model + 2 * P.nfreq + 2 * j, mk(0., 0.));
         }
     }
     __syncthreads();

@@ -45,6 +45,7 @@ struct RfLaunch {
     double qn;         // 1/sqrt(n)                      greens.cpp:147
     double wref;       // 2*pi*fref, fref = 1 Hz         greens.cpp:447, synrf.cpp:25
     int nsamp, nfreq, log2n, waveno, nout, out_off, out_stride, Lmax;
+    int nact;          // frequencies 0 .. nact-1 carry a Gauss-filter weight above 1e-24 (rf_host.h)
     int depth_input;   // 1: the `h` array holds depths z (single-model drop-in), 0: thicknesses
     int M;             // models per workgroup
 };

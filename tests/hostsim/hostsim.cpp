@@ -113,7 +113,7 @@ static int rf_hostsim_model(int nlay, const double *h, const double *vp, const d
     for (int i = 0; i < nlay; i++) rf_phase1_layer(S.data(), lo, nlay, i, h, vp, vs, rho, qp, qs, 0);
     for (int i = 0; i < nlay; i++) rf_phase2_interface(S.data(), lo, P, nlay, i, vp[0], vs[0]);
     std::vector<cd> spec(P.nfreq);
-    for (int j = 0; j < P.nfreq; j++) spec[j] = rf_phase3_task(S.data(), lo, P, nlay, j);
+    for (int j = 0; j < P.nfreq; j++) spec[j] = j < P.nact ? rf_phase3_task(S.data(), lo, P, nlay, j) : mk(0., 0.);
     double *X = S.data();
     for (int j = 0; j < P.nfreq; j++) st_cd(X + 2 * j, spec[j]);
     for (int i = nsamp / 2 + 1; i < nsamp; i++) rf_fft_hermitian(X, nsamp, i);
