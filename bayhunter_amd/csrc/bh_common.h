@@ -219,6 +219,38 @@ BH_DEV cm2 operator+(const cm2 &x, const cm2 &y)
     return r;
 }
 
+// real 2x2 times / plus complex 2x2: the interface coefficient matrices of a model are real when no
+// wave is post-critical anywhere in the stack (the teleseismic case), and a complex product with a
+// zero imaginary part is the real one
+struct rm2 {
+    double c11, c12, c21, c22;
+};
+BH_DEV cm2 operator*(const rm2 &x, const cm2 &y)
+{
+    cm2 r;
+    r.c11 = y.c11 * x.c11 + y.c21 * x.c12;
+    r.c12 = y.c12 * x.c11 + y.c22 * x.c12;
+    r.c21 = y.c11 * x.c21 + y.c21 * x.c22;
+    r.c22 = y.c12 * x.c21 + y.c22 * x.c22;
+    return r;
+}
+BH_DEV cm2 operator*(const cm2 &x, const rm2 &y)
+{
+    cm2 r;
+    r.c11 = x.c11 * y.c11 + x.c12 * y.c21;
+    r.c12 = x.c11 * y.c12 + x.c12 * y.c22;
+    r.c21 = x.c21 * y.c11 + x.c22 * y.c21;
+    r.c22 = x.c21 * y.c12 + x.c22 * y.c22;
+    return r;
+}
+BH_DEV cm2 operator+(const rm2 &x, const cm2 &y)
+{
+    cm2 r;
+    r.c11 = mk(x.c11 + y.c11.re, y.c11.im); r.c12 = mk(x.c12 + y.c12.re, y.c12.im);
+    r.c21 = mk(x.c21 + y.c21.re, y.c21.im); r.c22 = mk(x.c22 + y.c22.re, y.c22.im);
+    return r;
+}
+
 #if !defined(BH_HOSTSIM)
 #pragma clang fp contract(off)
 #endif

@@ -60,8 +60,9 @@ BH_HD RfLayout rf_layout(int Lmax, int nsamp)
     RfLayout lo;
     int nfreq = nsamp / 2 + 1;
     lo.L = Lmax;
-    lo.off_par = 2 * nfreq;            // [8][L]: d, vp, vs, rho, 1/(pi qp), 1/(pi qs), 1/vp^2, 1/vs^2
-    lo.off_coef = lo.off_par + 8 * Lmax; // [L][32]: rd, td, ru, tu of interface i (above layer i)
+    lo.off_par = 2 * nfreq;            // [9][L]: d, vp, vs, rho, 1/(pi qp), 1/(pi qs), 1/vp^2, 1/vs^2,
+                                       //         interface coefficients real?
+    lo.off_coef = lo.off_par + 9 * Lmax; // [L][32]: rd, td, ru, tu of interface i (above layer i)
     lo.off_sc = lo.off_coef + 32 * Lmax; // 16 scalars
     int need = lo.off_sc + 16;
     lo.per_model = need > 2 * nsamp ? need : 2 * nsamp;
@@ -81,6 +82,20 @@ BH_DEV cm2 ld_cm2(const double *p)
     cm2 m;
     m.c11 = ld_cd(p); m.c12 = ld_cd(p + 2); m.c21 = ld_cd(p + 4); m.c22 = ld_cd(p + 6);
     return m;
+}
+BH_DEV cm2 ld_m2(const double *p, const cm2 *) { return ld_cm2(p); }
+BH_DEV rm2 ld_m2(const double *p, const rm2 *)          // the real parts of a stored complex 2x2
+{
+    rm2 m;
+    m.c11 = p[0]; m.c12 = p[2]; m.c21 = p[4]; m.c22 = p[6];
+    return m;
+}
+BH_DEV cm2 to_cm2(const cm2 &m) { return m; }
+BH_DEV cm2 to_cm2(const rm2 &m)
+{
+    cm2 r;
+    r.c11 = mk(m.c11, 0.); r.c12 = mk(m.c12, 0.); r.c21 = mk(m.c21, 0.); r.c22 = mk(m.c22, 0.);
+    return r;
 }
 BH_DEV cm2 cm2_zero()
 {
@@ -257,14 +272,21 @@ BH_DEV void rf_phase2_interface(double *S, const RfLayout &lo, const RfLaunch &P
                   par[1 * lo.L + i], par[2 * lo.L + i], par[3 * lo.L + i], rd, td, ru, tu);
     }
     st_cm2(coef, rd); st_cm2(coef + 8, td); st_cm2(coef + 16, ru); st_cm2(coef + 24, tu);
+    const cm2 *four[4] = {&rd, &td, &ru, &tu};
+    bool real = true;
+    for (int k = 0; k < 4; k++)
+        real = real && four[k]->c11.im == 0. && four[k]->c12.im == 0. && four[k]->c21.im == 0. &&
+               four[k]->c22.im == 0.;
+    S[lo.off_par + 8 * lo.L + i] = real ? 1.0 : 0.0;
 }
 
 // ---- P3: one frequency of one model (greens.cpp:528-585 + compute_rf :377-395) ----------------------
 #if !defined(BH_HOSTSIM)
 #pragma clang fp contract(fast)
 #endif
-BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j,
-                         cd *zr_r = nullptr, cd *zr_z = nullptr)
+template <class M>
+BH_DEV cd rf_phase3_body(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j,
+                         cd *zr_r, cd *zr_z)
 {
     const double *par = S + lo.off_par;
     const double *coef = S + lo.off_coef;
@@ -296,20 +318,20 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
         cd e11 = cexp_(miwd * plc), e22 = cexp_(miwd * slc);
         const double *ci = coef + 32 * i, *cn = coef + 32 * (i + 1);
         cm2 nt;
-        if (i == 0) nt = ld_cm2(ci + 16);                       // nt = ru[1]
-        else nt = ld_cm2(ci + 16) + (ld_cm2(ci + 8) * nb) * q;  // ru + td*nb*q
+        if (i == 0) nt = to_cm2(ld_m2(ci + 16, (const M *)nullptr));                   // nt = ru[1]
+        else nt = ld_m2(ci + 16, (const M *)nullptr) + (ld_m2(ci + 8, (const M *)nullptr) * nb) * q;     // ru + td*nb*q
         {   // nb = e*nt*e, greens.cpp:829-845
             cd e12 = e11 * e22, e11s = e11 * e11, e22s = e22 * e22;
             nb.c11 = nt.c11 * e11s; nb.c12 = nt.c12 * e12; nb.c21 = nt.c21 * e12; nb.c22 = nt.c22 * e22s;
         }
         {   // q = inv(I - rd[i+1]*nb) * tu[i+1]
-            cm2 x = ld_cm2(cn) * nb;
+            cm2 x = ld_m2(cn, (const M *)nullptr) * nb;
             x.c11 = mk(1., 0.) - x.c11; x.c12 = mk(0., 0.) - x.c12;
             x.c21 = mk(0., 0.) - x.c21; x.c22 = mk(1., 0.) - x.c22;
             cd qi = crecip(x.c11 * x.c22 - x.c12 * x.c21);
             cm2 inv;
             inv.c11 = qi * x.c22; inv.c12 = (-qi) * x.c12; inv.c21 = (-qi) * x.c21; inv.c22 = qi * x.c11;
-            q = inv * ld_cm2(cn + 24);
+            q = inv * ld_m2(cn + 24, (const M *)nullptr);
         }
         if (i == 0) {                                             // g = e*q
             g.c11 = e11 * q.c11; g.c12 = e11 * q.c12; g.c21 = e22 * q.c21; g.c22 = e22 * q.c22;
@@ -340,6 +362,18 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
     cd cq = cexp_(mk(-0.25 * (wa * wa), -w * P.tshift)) * P.qgauss;
     if (zr_r) { *zr_r = arr_r * cq; *zr_z = arr_z * cq; }       // greens.cpp:393-394 (for iftr2)
     return crf * cq;
+}
+
+BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j,
+                         cd *zr_r = nullptr, cd *zr_z = nullptr)
+{
+    // all interface matrices of this model real (no post-critical wave anywhere): half the
+    // multiplications in the products with rd, td, ru, tu
+    const double *flag = S + lo.off_par + 8 * lo.L;
+    bool real = true;
+    for (int i = 0; i < nlay; i++) real = real && flag[i] != 0.0;
+    return real ? rf_phase3_body<rm2>(S, lo, P, nlay, j, zr_r, zr_z)
+                : rf_phase3_body<cm2>(S, lo, P, nlay, j, zr_r, zr_z);
 }
 
 #if !defined(BH_HOSTSIM)

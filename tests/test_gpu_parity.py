@@ -125,6 +125,34 @@ def test_rf_variants(lib, golden):
     print('rf variants worst |diff| = %.3e' % worst)
 
 
+def test_rf_post_critical_slowness(lib, oracle):
+    """Slowness 14 s/deg (0.126 s/km) is post-critical for vp > 7.9 km/s: the interface coefficient
+    matrices of such models are complex (the general form of the recursion), those of the slower
+    models real (the specialised form).  For an incident P wave the reference's delay sum then
+    takes the root of a negative number and the whole trace is NaN (reproduced); an incident SV
+    wave stays finite and exercises the complex form.  Both against the oracle."""
+    from bayhunter_amd.engine import ForwardEngine, RfSpec
+    H, VP, VS, RHO, nl = draw_models(96, (3, 9), seed=77)
+    x = np.linspace(-5, 35, 201)
+    post = (VP.max(axis=1) * 14.0 * 0.00899) > 1.0
+    assert 10 < post.sum() < 86                                   # both kinds present
+    for ref, wn in (('prf', 0), ('srf', 1)):
+        eng = ForwardEngine(rf=[RfSpec(ref, x, 1.0, 14.0)])
+        out, _ = eng.run(H, VP, VS, RHO, nl)
+        out = out.cpu().numpy()
+        want = np.stack([oracle.rf_model(H[b, :nl[b]], VP[b, :nl[b]], VS[b, :nl[b]], RHO[b, :nl[b]], p=14.0,
+                                         waveno=wn, nout=201) for b in range(96)])
+        ok = np.isfinite(want).all(axis=1)
+        # (where the rotation of the top layer is itself post-critical the reference returns NaN)
+        assert np.array_equal(np.isfinite(out).all(axis=1), ok)
+        if wn == 1:
+            assert (ok & post).sum() >= 5 and (ok & ~post).sum() >= 5, ((ok & post).sum(), (ok & ~post).sum())
+        else:
+            assert not (ok & post).any() and (~ok).sum() >= 5
+        scale = np.maximum(1.0, np.abs(want[ok]).max(axis=1, keepdims=True))
+        assert (np.abs(out[ok] - want[ok]) / scale).max() <= TOL_RF, ref
+
+
 def test_tutorial_dataset_single_model_dropins(lib, golden):
     """north_star: misfit within 1e-6 of SURF96/rfmini on the tutorial dataset, through the
     single-model drop-ins (bh_surfdisp96 / bh_synrf) behind the plugin classes."""
