@@ -97,7 +97,8 @@ class GpuEvaluator(object):
             # proposals of one iteration have ragged depths: let the engine group them by depth when
             # the batch is large enough for the lane kernel
             bt = self.joint._batch or self.joint._build_batch()
-            logL, misfits = self.joint.evaluate_batch(bt['eng'].reorder(dp, dn, ragged=True), noise=dz)
+            logL, misfits = self.joint.evaluate_batch(bt['eng'].reorder(dp, dn, ragged=True, depth=int(nlay.max())),
+                                                      noise=dz)
             outs[0][:B].copy_(logL, non_blocking=True)
             outs[1][:B].copy_(misfits, non_blocking=True)
             ev = torch.cuda.Event()

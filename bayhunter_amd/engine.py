@@ -32,10 +32,13 @@ class DeviceModels(object):
     """A batch of layered models resident in HBM: `packed` is [B, 4, Lmax] fp64 (h, vp, vs, rho
     rows of each model contiguous, zero padded), `nlay` int32 [B].  H/VP/VS/RHO are views."""
 
-    def __init__(self, packed, nlay, order=None):
+    def __init__(self, packed, nlay, order=None, depth=None):
         assert packed.dim() == 3 and packed.shape[1] == 4 and packed.is_contiguous()
         self.packed, self.nlay = packed, nlay
         self.B, self.Lmax = packed.shape[0], packed.shape[2]
+        # deepest model of the batch when the host knows it (<= Lmax): the kernels size their LDS
+        # images and pick the team width by it instead of by the allocated row length
+        self.depth = None if depth is None else max(1, min(int(depth), self.Lmax))
         self.H, self.VP, self.VS, self.RHO = (packed[:, i, :] for i in range(4))
         # Processing order of the dispersion searches (int32 permutation, ForwardEngine.reorder):
         # the data stay where they are and results land in the caller's rows.
@@ -130,10 +133,11 @@ class ForwardEngine(object):
         f64 = torch.float64
         parts = [self._as_dev(x, f64) for x in (H, VP, VS, RHO)]
         packed = torch.stack(parts, dim=1).contiguous()
+        depth = int(np.max(nlay)) if isinstance(nlay, np.ndarray) and nlay.size else None
         nlay = self._as_dev(nlay, torch.int32)
-        return self.reorder(packed, nlay)
+        return self.reorder(packed, nlay, depth=depth)
 
-    def reorder(self, packed, nlay, ragged=None):
+    def reorder(self, packed, nlay, ragged=None, depth=None):
         """DeviceModels for a packed [B, 4, Lmax] device tensor, with a processing order for large
         batches: the lanes of a wave (and the teams sharing one) run their searches in lock step, so
         neighbours should be alike.  Deepest models first (the layer loop runs to the deepest model
@@ -149,7 +153,7 @@ class ForwardEngine(object):
             # one sort: depth (descending) is the major key, travel time (< 1e4 s) the minor one
             key = (tt.clamp(0., 9.9e3) - nlay.to(torch.float64) * 1.0e4).to(torch.float32)
             order = torch.argsort(key).to(torch.int32)
-        return DeviceModels(packed, nlay, order)
+        return DeviceModels(packed, nlay, order, depth)
 
     def alloc_out(self, B):
         out = torch.empty((B, self.row), dtype=torch.float64, device=self.device)
@@ -164,8 +168,11 @@ class ForwardEngine(object):
         if models.packed.device != self.device:
             raise ValueError("models live on %s, engine on %s" % (models.packed.device, self.device))
         H, VP, VS, RHO, nlay = models.H, models.VP, models.VS, models.RHO, models.nlay
-        B, Lmax = models.B, models.Lmax
-        mstride = 4 * Lmax
+        B = models.B
+        mstride = 4 * models.Lmax
+        Lmax = models.Lmax
+        if models.depth is not None:                 # even, so that rows can be fetched two layers at a time
+            Lmax = min(models.Lmax, models.depth + (models.depth % 2))
         if out is None or err is None:
             out, err = self.alloc_out(B)
         st = torch.cuda.current_stream(self.device) if stream is None else stream

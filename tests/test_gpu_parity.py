@@ -125,6 +125,25 @@ def test_rf_variants(lib, golden):
     print('rf variants worst |diff| = %.3e' % worst)
 
 
+def test_batch_depth_hint_changes_nothing(lib):
+    """Rows allocated for 31 layers holding models of at most 9: with the depth known the kernels
+    size their LDS for 10 layers (and may pick another team width); values are the same bits."""
+    import torch
+    from bayhunter_amd.engine import DeviceModels, ForwardEngine, RfSpec, SwdSpec
+    H, VP, VS, RHO, nl = draw_models(3000, (2, 9), seed=5, sorted_vs=False)
+    pad = lambda a: np.concatenate([a, np.zeros((a.shape[0], 31 - a.shape[1]))], axis=1)
+    H, VP, VS, RHO = pad(H), pad(VP), pad(VS), pad(RHO)
+    eng = ForwardEngine(swd=[SwdSpec('rdispph', np.linspace(1, 41, 21)), SwdSpec('ldispgr', np.linspace(2, 30, 9))],
+                        rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
+    with_hint = eng.upload(H, VP, VS, RHO, nl)
+    assert with_hint.depth == 9
+    plain = DeviceModels(with_hint.packed, with_hint.nlay)
+    a, ea = eng.run(with_hint)
+    b, eb = eng.run(plain)
+    torch.cuda.synchronize()
+    assert torch.equal(ea, eb) and torch.equal(a.nan_to_num(nan=-1.0), b.nan_to_num(nan=-1.0))
+
+
 def test_rf_post_critical_slowness(lib, oracle):
     """Slowness 14 s/deg (0.126 s/km) is post-critical for vp > 7.9 km/s: the interface coefficient
     matrices of such models are complex (the general form of the recursion), those of the slower
@@ -384,7 +403,8 @@ def test_engine_corner_cases(lib, oracle):
     assert out.shape == (0, 222) and err.shape == (0, 1)
     # model on the wrong device / bad shapes are host errors, not kernel faults
     with pytest.raises(Exception):
-        eng2.run(np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)), np.ones(3, dtype=np.int32))
+        eng2.run(np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)), np.zeros((3, 101)),
+                 np.full(3, 101, dtype=np.int32))                     # more than NL = 100 layers
 
 
 def test_division_selftest(lib):
