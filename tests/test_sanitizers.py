@@ -1,0 +1,33 @@
+"""Sanitizers on the CPU build of the chain pool's host code (csrc/chains.cpp; GPU sanitizers are not
+available on the pool): AddressSanitizer + UBSan for memory and arithmetic errors, ThreadSanitizer
+for the helper-thread protocol (spinning workers, job hand-over, pools of different size stepped
+alternately).  The driver's checksum must not depend on the number of threads."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+SRC = [os.path.join(ROOT, 'tests', 'sanitize', 'chains_driver.cpp'),
+       os.path.join(ROOT, 'bayhunter_amd', 'csrc', 'chains.cpp')]
+
+
+def _run(tmp_path, flags, threads, env=None):
+    exe = str(tmp_path / ('driver_' + '_'.join(f.strip('-=').replace(',', '_') for f in flags)))
+    subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-pthread', '-ffp-contract=off'] + flags + SRC + ['-o', exe],
+                   check=True)
+    e = dict(os.environ, BH_CHAIN_SPIN_US='200')
+    e.update(env or {})
+    r = subprocess.run([exe, str(threads)], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'runtime error' not in r.stderr and 'WARNING: ThreadSanitizer' not in r.stderr, r.stderr[-4000:]
+    return [l for l in r.stdout.splitlines() if l.startswith('checksum')][0]
+
+
+def test_chain_pool_host_code_under_asan_ubsan_and_tsan(tmp_path):
+    plain1 = _run(tmp_path, [], 1)
+    asan = _run(tmp_path, ['-fsanitize=address,undefined', '-fno-omit-frame-pointer'], 8,
+                env={'ASAN_OPTIONS': 'detect_leaks=1', 'UBSAN_OPTIONS': 'print_stacktrace=1'})
+    tsan = _run(tmp_path, ['-fsanitize=thread'], 8, env={'TSAN_OPTIONS': 'halt_on_error=1'})
+    assert plain1 == asan == tsan
