@@ -31,3 +31,16 @@ def test_chain_pool_host_code_under_asan_ubsan_and_tsan(tmp_path):
                 env={'ASAN_OPTIONS': 'detect_leaks=1', 'UBSAN_OPTIONS': 'print_stacktrace=1'})
     tsan = _run(tmp_path, ['-fsanitize=thread'], 8, env={'TSAN_OPTIONS': 'halt_on_error=1'})
     assert plain1 == asan == tsan
+
+
+def test_device_solver_cores_under_asan_ubsan(tmp_path):
+    """swd_core.h / swd_team.h / rf_core.h compiled for the host (tests/hostsim) over 220 pseudo-random
+    models incl. 1 and 100 layers, water layer, LVZ, modes 1-3, 60 periods, four FFT lengths."""
+    src = os.path.join(ROOT, 'tests', 'sanitize', 'cores_driver.cpp')
+    exe = str(tmp_path / 'cores')
+    subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-ffp-contract=off', '-fsanitize=address,undefined',
+                    '-fno-omit-frame-pointer', src, '-o', exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, UBSAN_OPTIONS='print_stacktrace=1'))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'cores ok' in r.stdout and 'runtime error' not in r.stderr, r.stderr[-4000:]
