@@ -103,6 +103,8 @@ _SIGS = {
     "bh_chains_set_threads": (C.c_int, [_vp, C.c_int]),
     "bh_chains_propose": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
     "bh_chains_accept": (C.c_int, [_vp, _vp, _vp]),
+    "bh_chains_moves": (C.c_int, [_vp, _vp]),
+    "bh_chains_accepted": (C.c_int, [_vp, _vp]),
     "bh_chains_done": (C.c_int, [_vp]),
     "bh_chains_iteration": (C.c_long, [_vp]),
     "bh_chains_counters": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

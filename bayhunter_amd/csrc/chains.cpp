@@ -160,7 +160,7 @@ struct Chain {
     double propdist[5], accepted[5], proposed[5];
     long nstored, lastmoditer;
     // proposal of the running iteration
-    int pn, move, valid, slot;
+    int pn, move, valid, slot, took;     // took: the last accept replaced the current model by the proposal
     Span pvs, pz;
     double pnoise[MAXN], pvpvs, dvs2;
 };
@@ -531,6 +531,7 @@ bool decide(bh_chain_pool *p, int ci, Chain &c, const double *logL, const double
 {
     const bh_chain_config &g = p->cfg;
     bool ok = true;
+    c.took = 0;
     if (!c.valid) return true;                      // iterate() returned before anything else
     int par = PAR_OF_MOVE[c.move];
     c.proposed[par] += 1;
@@ -548,6 +549,7 @@ bool decide(bh_chain_pool *p, int ci, Chain &c, const double *logL, const double
         }
     }
     if (u < alpha) {
+        c.took = 1;
         take_proposal(p, c, logL, misfits);
         ok = store(p, ci, c);
         c.accepted[par] += 1;
@@ -598,7 +600,7 @@ int bh_chains_create(const bh_chain_config *cfg, int nchains, const unsigned *se
         c.vpvs = c.pvpvs = 0.0; c.like = 0.0; c.dvs2 = 0.0;
         for (int k = 0; k < 5; k++) { c.propdist[k] = cfg->propdist[k]; c.accepted[k] = c.proposed[k] = 0.0; }
         c.nstored = 0; c.lastmoditer = p->iiter;
-        c.pn = 0; c.move = -1; c.valid = 0; c.slot = -1;
+        c.pn = 0; c.move = -1; c.valid = 0; c.slot = -1; c.took = 0;
     }
     *out = p;
     return BH_OK;
@@ -660,6 +662,7 @@ int bh_chains_accept(bh_chain_pool *p, const double *logL, const double *misfits
         for_chains(p, [=](int i) {
             Chain &c = p->chains[i];
             take_proposal(p, c, logL, misfits);
+            c.took = 1;
             if (!store(p, i, c)) badp[i] = 1;
         });
         p->stage = 2;
@@ -674,6 +677,22 @@ int bh_chains_accept(bh_chain_pool *p, const double *logL, const double *misfits
             return bh::fail_arg_("bh_chains_accept: a chain accepted more models than its storage holds "
                                  "(nmodels = iterations * max(acceptance) / 100, like the reference's arrays)");
         }
+    return BH_OK;
+}
+
+int bh_chains_moves(const bh_chain_pool *p, int *move)
+{
+    if (!p || !move) return bh::fail_arg_("bh_chains_moves: NULL argument");
+    for (const Chain &c : p->chains)
+        if (c.valid && c.slot >= 0) move[c.slot] = c.move;
+    return BH_OK;
+}
+
+int bh_chains_accepted(const bh_chain_pool *p, int *flag)
+{
+    if (!p || !flag) return bh::fail_arg_("bh_chains_accepted: NULL argument");
+    for (const Chain &c : p->chains)
+        if (c.valid && c.slot >= 0) flag[c.slot] = c.took;
     return BH_OK;
 }
 

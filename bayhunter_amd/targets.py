@@ -295,6 +295,15 @@ class JointTarget(object):
                 RHO = (torch.as_tensor(VP) * 0.32 + 0.77) * (torch.as_tensor(VS) > 0) \
                     if isinstance(VP, torch.Tensor) else np.where(np.asarray(VS) > 0, np.asarray(VP) * 0.32 + 0.77, 0.0)
             out, err = eng.run(H, VP, VS, RHO, nlay, stream=stream)
+        return self.likelihood_batch(out, err, noise, stream=stream)
+
+    def likelihood_batch(self, out, err, noise, stream=None):
+        """The fused likelihood on modelled data that are already on the device: out[B, row] and
+        err[B, nswd] as ForwardEngine.run returns them (e.g. rows kept from an earlier launch),
+        noise[B, 2*ntargets].  Returns (logL[B], misfits[B, ntargets+1])."""
+        import torch
+        bt = self._batch or self._build_batch()
+        eng = bt['eng']
         B = out.shape[0]
         noise = eng._as_dev(noise, torch.float64)
         logL = torch.empty(B, dtype=torch.float64, device=eng.device)

@@ -260,6 +260,12 @@ int  bh_chains_propose(bh_chain_pool *pool, int Lmax, double *packed, int *nlay,
 /* logL[count], misfits[count][ntargets+1] of the models handed out by the last propose: draw u,
  * accept or reject, store, adapt the proposal widths, advance the iteration counter. */
 int  bh_chains_accept(bh_chain_pool *pool, const double *logL, const double *misfits);
+/* Per model handed out by the last propose (k = 0..count-1): the move that produced it -- 0 vs of a
+ * nucleus, 1 depth of a nucleus, 2 birth, 3 death, 4 noise parameter, 5 vp/vs, -1 initial model.
+ * A noise move (4) leaves the layered model as it was.  After accept: whether the proposal replaced
+ * the chain's current model. */
+int  bh_chains_moves(const bh_chain_pool *pool, int *move);
+int  bh_chains_accepted(const bh_chain_pool *pool, int *flag);
 int  bh_chains_done(const bh_chain_pool *pool);            /* 1 when iiter reached iter_main  */
 long bh_chains_iteration(const bh_chain_pool *pool);       /* iiter, starts at -iter_burnin   */
 /* per-chain bookkeeping; any pointer may be NULL.  naccepted = rows stored so far (the reference's

@@ -268,3 +268,37 @@ def test_threads_and_pool_interleaving_do_not_change_chains(lib):
         assert np.array_equal(other.counters()[0], ref.counters()[0][:n])
         for k in ('models', 'likes', 'noise', 'vpvs', 'iter'):
             assert np.array_equal(getattr(other, k), getattr(ref, k)[:n], equal_nan=True), k
+
+
+def test_move_and_acceptance_queries(lib):
+    """bh_chains_moves / bh_chains_accepted: per model of the last batch, which move produced it and
+    whether it became the chain's current model; consistent with the stored samples."""
+    from bayhunter_amd import _lib
+    from chain_scenario import joint_target
+    from bayhunter_amd.chains import ChainPool
+    case = CASES['tutorial']
+    seen_moves, taken = set(), 0
+
+    def toy(packed, nlay, noise):
+        d = packed[:, 2, 0] - 3.0
+        return -30. * d * d - noise[:, 3], np.zeros((packed.shape[0], 3))
+    ip = dict(case['initparams'], iter_burnin=60, iter_main=20, acceptance=(40, 100))
+    pool = ChainPool(joint_target(DATA), initparams=ip, modelpriors=case['priors'], seeds=np.arange(40), evaluator=toy,
+                     groups=1)
+    g = pool.groups[0]
+    first = True
+    while not g.done():
+        n = g.propose()
+        moves = np.full(n, -9, dtype=np.int32)
+        _lib.check(lib.bh_chains_moves(g.handle, moves.ctypes.data))
+        assert np.all(moves == -1) if first else (np.all(moves >= 0) and np.all(moves <= 5))
+        seen_moves.update(moves.tolist())
+        logL, mis = toy(g.packed[:n], g.nlay[:n], g.noise[:n])
+        g.accept(np.ascontiguousarray(logL), mis)
+        flags = np.full(n, -9, dtype=np.int32)
+        _lib.check(lib.bh_chains_accepted(g.handle, flags.ctypes.data))
+        assert set(flags.tolist()) <= {0, 1} and (not first or np.all(flags == 1))
+        taken += int(flags.sum())
+        first = False
+    assert seen_moves == {-1, 0, 1, 2, 3, 4, 5}
+    assert taken == int(pool.counters()[0].sum())              # every stored sample was reported as taken
