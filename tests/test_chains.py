@@ -302,3 +302,61 @@ def test_move_and_acceptance_queries(lib):
         first = False
     assert seen_moves == {-1, 0, 1, 2, 3, 4, 5}
     assert taken == int(pool.counters()[0].sum())              # every stored sample was reported as taken
+
+
+def test_hunt_script_reads_reference_config_and_writes_results(oracle, tmp_path):
+    """tools/hunt.py: a BayHunter config.ini (the tutorial's values) + observed data files -> chain
+    pool -> the reference's result files; the forward model is the oracle here (no GPU)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import hunt
+    ini = tmp_path / 'config.ini'
+    ini.write_text("""[modelpriors]
+vpvs = 1.4, 2.1
+layers = 1, 20
+vs = 2, 5
+z = 0, 60
+mohoest = None
+rfnoise_corr = 0.9
+swdnoise_corr = 0.
+rfnoise_sigma = 1e-5, 0.05
+swdnoise_sigma = 1e-5, 0.05
+
+[initparams]
+nchains = 3
+iter_burnin = (10 * 4)
+iter_main = (10 * 2)
+propdist = 0.015, 0.015, 0.015, 0.005, 0.005
+acceptance = 40, 45
+thickmin = 0.1
+lvz = None
+hvz = None
+rcond= 1e-5
+station = 'st3'
+savepath = '%s'
+maxmodels = 50000
+""" % str(tmp_path / 'results'))
+    priors, ip = hunt.load_params(str(ini))
+    assert priors['vpvs'] == (1.4, 2.1) and priors['mohoest'] is None and priors['swdnoise_corr'] == 0.0
+    assert ip['iter_burnin'] == 40 and ip['station'] == 'st3' and ip['acceptance'] == (40, 45)
+    joint = [None]
+
+    def evaluator(packed, nlay, noise):
+        return oracle_evaluator(joint[0])(packed, nlay, noise)
+    real_build = hunt.build_targets
+
+    def build(specs, gauss=None, p=None):
+        j = real_build(specs, gauss, p)
+        for t in j.targets:
+            t.update_plugin(OraclePlugin(oracle, t.obsdata.x, t.ref))
+        joint[0] = j
+        return j
+    hunt.build_targets = build
+    try:
+        pool = hunt.main([str(ini), '--target', 'rdispph=' + os.path.join(DATA, 'st3_rdispph.dat'),
+                          '--target', 'prf=' + os.path.join(DATA, 'st3_prf.dat'), '--seed', '5', '--full-storage'],
+                         evaluator=evaluator)
+    finally:
+        hunt.build_targets = real_build
+    files = sorted(os.listdir(str(tmp_path / 'results' / 'data')))
+    assert 'st3_config.pkl' in files and sum(f.endswith('.npy') for f in files) == 30
+    assert pool.nchains == 3 and list(pool.seeds) == [np.random.RandomState(5).randint(1000) for _ in range(1)] + list(pool.seeds[1:])
