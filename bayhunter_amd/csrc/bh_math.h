@@ -9,7 +9,12 @@
 //   bh_sincos : one-step Cody-Waite reduction by pi/2 (fdlibm's 33+53-bit split, exact with FMA)
 //               valid for |x| < 1e4 (max error 1.04 ulp, 0.79 below 300), then the classic __kernel_sin/__kernel_cos minimax
 //               polynomials on [-pi/4, pi/4] with the reduction tail folded in.  Larger arguments
-//               (never produced by physical models: p = k_z * d) fall back to the slow path.
+//               (never produced by physical models: p = k_z * d) take an exact-product reduction
+//               with fdlibm's three 33-bit pieces of pi/2 up to 1e12 and are NaN beyond (a phase
+//               of 1e12 rad is no seismological model; the search then reports "no root").  The
+//               device library's sincos is deliberately not used: inlined into the recursions its
+//               Payne-Hanek path cost registers in every kernel (spills in rf_kernel and the team
+//               kernels) although it never ran.
 //   bh_exp    : k = rint(x/ln2), r = x - k*ln2 (hi/lo, exact with FMA), degree-13 polynomial,
 //               scaled by 2^k with ldexp; saturates like exp() outside [-745, 709].
 #pragma once
@@ -21,12 +26,10 @@ namespace bh {
 BH_DEV double bh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 BH_DEV double bh_rint(double x) { return __builtin_rint(x); }
 BH_DEV double bh_ldexp(double x, int k) { return __builtin_ldexp(x, k); }
-BH_DEV void bh_sincos_slow(double x, double *s, double *c) { *s = std::sin(x); *c = std::cos(x); }
 #else
 BH_DEV double bh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 BH_DEV double bh_rint(double x) { return __builtin_rint(x); }
 BH_DEV double bh_ldexp(double x, int k) { return __builtin_amdgcn_ldexp(x, k); }
-BH_DEV void bh_sincos_slow(double x, double *s, double *c) { ::sincos(x, s, c); }
 #endif
 
 #if defined(BH_HOSTSIM) && defined(BH_HOSTSIM_GLIBC_MATH)
@@ -40,16 +43,39 @@ BH_DEV void bh_sincos(double x, double *sn, double *cs)
     const double INVPIO2 = 6.36619772367581382433e-01;  // 2/pi
     const double PIO2_1 = 1.57079632673412561417e+00;   // first 33 bits of pi/2
     const double PIO2_1T = 6.07710050650619224932e-11;  // pi/2 - PIO2_1
-    if (!(fabs(x) < 1.0e4)) {  // also NaN/Inf; beyond 1e4 the two-constant reduction exceeds 1 ulp
-        bh_sincos_slow(x, sn, cs);
+    double y0, y1;
+    int n;
+    if (fabs(x) < 1.0e4) {     // beyond 1e4 the two-constant reduction exceeds 1 ulp
+        double fn = bh_rint(x * INVPIO2);
+        double r = bh_fma(-fn, PIO2_1, x);  // exact: fn < 2^20, PIO2_1 has 33 significant bits
+        double w = fn * PIO2_1T;
+        y0 = r - w;
+        y1 = (r - y0) - w;                  // tail: x - fn*pi/2 = y0 + y1
+        n = (int)fn;
+    } else if (fabs(x) < 1.0e12) {
+        // fn < 2^40 splits into fh (a multiple of 2^20, <= 20 significant bits) + fl (|fl| <= 2^19):
+        // every product with a 33-bit piece of pi/2 is exact, x - fh*PIO2_1 is exact (Sterbenz), and
+        // the remaining terms are summed in double-double (two-sum).  152 bits of pi/2 in total.
+        const double PIO2_2 = 6.07710050630396597660e-11, PIO2_3 = 2.02226624871116645580e-21,
+                     PIO2_3T = 8.47842766036889956997e-32;
+        double fn = bh_rint(x * INVPIO2);
+        double fh = bh_rint(fn * 9.5367431640625e-07) * 1048576.0, fl = fn - fh;
+        double hi = x - fh * PIO2_1, lo = 0.0;
+        const double terms[5] = {fl * PIO2_1, fh * PIO2_2, fl * PIO2_2, fh * PIO2_3, fl * PIO2_3};
+        for (int k = 0; k < 5; k++) {
+            double t = -terms[k];
+            double s = hi + t, bb = s - hi;
+            lo += (hi - (s - bb)) + (t - bb);
+            hi = s;
+        }
+        lo -= fn * PIO2_3T;
+        y0 = hi + lo;
+        y1 = (hi - y0) + lo;
+        n = (int)(fn - 4.0 * bh_rint(fn * 0.25));   // quadrant; fn itself does not fit an int
+    } else {                                        // 1e12 and beyond, Inf, NaN
+        *sn = *cs = __builtin_nan("");
         return;
     }
-    double fn = bh_rint(x * INVPIO2);
-    double r = bh_fma(-fn, PIO2_1, x);  // exact: fn < 2^20, PIO2_1 has 33 significant bits
-    double w = fn * PIO2_1T;
-    double y0 = r - w;
-    double y1 = (r - y0) - w;           // tail: x - fn*pi/2 = y0 + y1
-    int n = (int)fn;
     double z = y0 * y0;
     // __kernel_sin(y0, y1, 1)
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,

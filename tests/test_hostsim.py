@@ -84,10 +84,18 @@ def test_math_accuracy(hostsim_devmath):
         x = rs.uniform(lo, hi, 400000)
         s, c = hostsim_devmath.sincos(x)
         assert _ulp_err(s, x, np.sin).max() <= bound and _ulp_err(c, x, np.cos).max() <= bound
-    x = np.array([0.0, 1e-300, 1e7, -1e9, np.pi / 2])
+    # 1e4 .. 1e12: the exact-product reduction (no device-library call); also next to multiples of
+    # pi/2, where the reduced argument cancels almost completely
+    for lo, hi in ((1e4, 1.6e6), (1.6e6, 1e9), (1e9, 0.999e12)):
+        x = rs.uniform(lo, hi, 300000) * rs.choice([-1.0, 1.0], 300000)
+        k = np.round(x[:100000] / (np.pi / 2))
+        x[:100000] = np.nextafter(k * (np.pi / 2), np.inf) + k * 6.123233995736766e-17 * rs.choice([0, 1], 100000)
+        s, c = hostsim_devmath.sincos(x)
+        assert _ulp_err(s, x, np.sin).max() <= 1.1 and _ulp_err(c, x, np.cos).max() <= 1.1, (lo, hi)
+    x = np.array([0.0, 1e-300, 1e7, -1e9, np.pi / 2, 9.99e11])
     s, c = hostsim_devmath.sincos(x)
     assert np.allclose(s, np.sin(x), rtol=0, atol=1e-15) and np.allclose(c, np.cos(x), rtol=0, atol=1e-15)
-    assert all(np.isnan(v).all() for v in hostsim_devmath.sincos(np.array([np.inf, np.nan])))
+    assert all(np.isnan(v).all() for v in hostsim_devmath.sincos(np.array([np.inf, np.nan, 1e12, -3e300])))
     for lo, hi in ((-60, 0), (-700, 700)):
         x = rs.uniform(lo, hi, 400000)
         assert _ulp_err(hostsim_devmath.exp(x), x, np.exp).max() <= 0.95
