@@ -308,7 +308,11 @@ BH_DEV float swd_powf(float x, float y) { return (float)::pow((double)x, (double
 // sphere, surfdisp96.f:486-553, both calls (iflag 0 then iflag 1 for this lane's wave type) folded
 // into one pass: d,a,b are transformed, rho is scaled by btp**(-5) (Love) / btp**(-2.275) (Rayleigh).
 template <class Lay>
+#if defined(BH_HOSTSIM)
 BH_DEV void swd_sphere(Lay &lay, int mmax, int ifunc)
+#else
+__device__ __noinline__ void swd_sphere(Lay &lay, int mmax, int ifunc)
+#endif
 {
     double ar = 6370.0, dr = 0.0, r0 = ar, r1, z0, z1, tmp;
     lay.set_d(mmax - 1, 1.0f);
