@@ -68,7 +68,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + SOURCES + ["-o", LIB_PATH]
+    extra = os.environ.get("BH_EXTRA_HIPCC_FLAGS", "").split()      # compiler experiments
+    cmd = [hipcc] + HIPCC_FLAGS + extra + SOURCES + ["-o", LIB_PATH]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, cwd=CSRC, check=True)
