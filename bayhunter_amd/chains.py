@@ -73,44 +73,57 @@ class GpuEvaluator(object):
         self._pin = {}
 
     def buffers(self, rows, Lmax, ntargets):
+        """One pinned block per group, [packed | noise | nlay | chain], so that a batch goes up in ONE
+        copy (every host->device call costs ~60 us of host time, which is what a small pool waits
+        for); results come down in one block [logL | misfits] as well."""
         torch = self.torch
-        bufs = [torch.zeros((rows, 4, Lmax), dtype=torch.float64).pin_memory(),
-                torch.zeros(rows, dtype=torch.int32).pin_memory(),
-                torch.zeros((rows, 2 * ntargets), dtype=torch.float64).pin_memory(),
-                torch.zeros(rows, dtype=torch.int32).pin_memory()]
-        outs = (torch.zeros(rows, dtype=torch.float64).pin_memory(),
-                torch.zeros((rows, ntargets + 1), dtype=torch.float64).pin_memory())
-        views = tuple(b.numpy() for b in bufs)
-        self._pin[views[0].ctypes.data] = (bufs, outs, torch.cuda.Stream(device=self.device))
-        return views
+        nd = rows * 4 * Lmax + rows * 2 * ntargets          # doubles in front
+        block = torch.zeros(nd + rows, dtype=torch.float64).pin_memory()      # + 2 int32 per row
+        host = block.numpy()
+        packed = host[:rows * 4 * Lmax].reshape(rows, 4, Lmax)
+        noise = host[rows * 4 * Lmax:nd].reshape(rows, 2 * ntargets)
+        ints = host[nd:].view(np.int32)
+        nlay, chain = ints[:rows], ints[rows:2 * rows]
+        outs = torch.zeros(rows * (ntargets + 2), dtype=torch.float64).pin_memory()
+        self._pin[packed.ctypes.data] = dict(block=block, outs=outs, rows=rows, Lmax=Lmax, T=ntargets, nd=nd,
+                                             stream=torch.cuda.Stream(device=self.device))
+        return packed, nlay, noise, chain
 
     def submit(self, group, packed, nlay, noise):
         torch = self.torch
         B = packed.shape[0]
         if B == 0:
             return None
-        bufs, outs, stream = self._pin[packed.ctypes.data]
-        with torch.cuda.stream(stream):
-            dp = bufs[0][:B].to(self.device, non_blocking=True)
-            dn = bufs[1][:B].to(self.device, non_blocking=True)
-            dz = bufs[2][:B].to(self.device, non_blocking=True)
-            # proposals of one iteration have ragged depths: let the engine group them by depth when
-            # the batch is large enough for the lane kernel
+        st = self._pin[packed.ctypes.data]
+        rows, Lmax, T, nd = st['rows'], st['Lmax'], st['T'], st['nd']
+        with torch.cuda.stream(st['stream']):
+            # small pools: the whole block in one copy; large ones: only the used part of each section
+            if rows <= 16384:
+                d = st['block'].to(self.device, non_blocking=True)
+                dp = d[:rows * 4 * Lmax].view(rows, 4, Lmax)[:B]
+                dz = d[rows * 4 * Lmax:nd].view(rows, 2 * T)[:B]
+                dn = d[nd:].view(torch.int32)[:B]
+            else:
+                blk = st['block']
+                dp = blk[:B * 4 * Lmax].to(self.device, non_blocking=True).view(B, 4, Lmax)
+                dz = blk[rows * 4 * Lmax:rows * 4 * Lmax + B * 2 * T].to(self.device, non_blocking=True).view(B, 2 * T)
+                dn = blk[nd:].view(torch.int32)[:B].to(self.device, non_blocking=True)
+            # proposals of one iteration have ragged depths: the engine groups large batches by depth
             bt = self.joint._batch or self.joint._build_batch()
             logL, misfits = self.joint.evaluate_batch(bt['eng'].reorder(dp, dn, ragged=True, depth=int(nlay.max())),
                                                       noise=dz)
-            outs[0][:B].copy_(logL, non_blocking=True)
-            outs[1][:B].copy_(misfits, non_blocking=True)
+            st['outs'][:B * (T + 2)].copy_(torch.cat((logL, misfits.reshape(-1))), non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record(stream)
-        return ev, outs, B
+            ev.record(st['stream'])
+        return ev, st['outs'], B, T
 
     def collect(self, ticket):
         if ticket is None:
             return np.zeros(0), np.zeros((0, self.joint.ntargets + 1))
-        ev, outs, B = ticket
+        ev, outs, B, T = ticket
         ev.synchronize()
-        return outs[0].numpy()[:B], outs[1].numpy()[:B]
+        host = outs.numpy()
+        return host[:B], host[B:B * (T + 2)].reshape(B, T + 1)
 
 
 class _Group(object):
