@@ -2,7 +2,7 @@
 sample -- how many dispersion values are bit-identical, max RF difference."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bayhunter_amd import _lib
 from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
 from bayhunter_amd.synthetic import draw_models

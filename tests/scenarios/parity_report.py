@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec  # noqa: E402
 from bayhunter_amd.synthetic import draw_models  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402

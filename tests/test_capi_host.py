@@ -1,6 +1,7 @@
 """CPU tier: the C-ABI library loads, exports every symbol the header declares, refuses to compute
 without a GPU (no CPU fallback), and the Python host side mirrors the reference's plugin contract."""
 import os
+import sys
 import re
 import subprocess
 
@@ -48,6 +49,19 @@ def test_product_never_touches_oracle():
     from bayhunter_amd import _lib
     out = subprocess.run(['ldd', _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert 'oracle' not in out and 'hostsim' not in out
+    # helper scripts are not test code either: the diagnostics that need the oracle live in tests/
+    for f in os.listdir(os.path.join(ROOT, 'tools')):
+        if f.endswith(('.py', '.sh')):
+            src = open(os.path.join(ROOT, 'tools', f)).read()
+            assert 'pyoracle' not in src and 'import oracle' not in src and 'from oracle' not in src, f
+    # bench.py: only the cpu_baseline leg (its worker function) may name the oracle
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, 'bench.py')).read())
+    users = {fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef)
+             and any('oracle' in ast.dump(n) for n in ast.walk(fn) if isinstance(n, (ast.Import, ast.ImportFrom)))}
+    assert users and users <= {'_cpu_worker', 'cpu_baseline'}, users
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and 'oracle' in ast.dump(n)]
+    assert not top
 
 
 def test_arg_validation_without_gpu(lib):
@@ -101,3 +115,13 @@ def test_plugin_contract():
     assert bh.RFminiModRF(np.linspace(-5, 35, 201), 'srf').modelparams['wtype'] == 'SV'
     with pytest.raises(ValueError):
         bh.RFminiModRF(np.array([0., 0.2, 0.5, 0.6]), 'prf')
+
+
+def test_bench_evaluation_counts_are_the_oracles():
+    """bench.py normalises its flop figure by the reference path's evaluation count; the
+    committed table must be what the oracle's counter says for the default workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+    import bench
+    import count_dltar
+    counts, lmean = count_dltar.count(bench.WORKLOADS['joint10'])
+    assert (counts, lmean) == bench.N_DLTAR['joint10']

@@ -3,7 +3,7 @@ vectors.
 
 Tolerances (fp64 path).  Every IEEE operation of the search is replayed exactly; the only
 difference to the reference is the device libm (sin/cos/exp differ from glibc in the last bit).
-Measured on MI355X with tools/parity_report.py (8 sets x 2048 models, profiles/parity_r01.txt):
+Measured on MI355X with tests/scenarios/parity_report.py (8 sets x 2048 models, profiles/parity_r01.txt):
   * models with velocity increasing with depth (the tutorial, the bench workloads): all four
     dispersion targets 100 % bit-identical
   * models with low-velocity zones: the Rayleigh period equation is ill-conditioned near its root,
