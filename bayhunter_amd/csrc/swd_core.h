@@ -337,6 +337,30 @@ __device__ __noinline__ void swd_sphere(Lay &lay, int mmax, int ifunc)
     lay.set_d(mmax - 1, 0.0f);
 }
 
+// Results are real*4 values promoted to fp64 (surfdisp96.f:298,303,306).  A lane finishes its periods
+// one at a time; storing them in pairs (16 bytes) halves the scattered 8-byte stores, which the
+// memory side tallies at 32-64 bytes each.
+BH_DEV void swd_store_pair(double *p, float a, float b)
+{
+#if defined(BH_HOSTSIM)
+    p[0] = (double)a; p[1] = (double)b;
+#else
+    typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));
+    d2_t v;
+    v.x = (double)a; v.y = (double)b;
+    *(d2_t *)p = v;
+#endif
+}
+BH_DEV void swd_put(double *out, int k, int kmax, float v, float &pend)      // k: 1-based period
+{
+    if (k & 1) {
+        if (k == kmax) out[k - 1] = (double)v;
+        else pend = v;
+    } else {
+        swd_store_pair(out + k - 2, pend, v);
+    }
+}
+
 // ---- the search ----------------------------------------------------------------------------------
 struct SwdTargetDev {
     int iwave, igr, mode, iflsph, nper, per_off, out_off, _pad;
@@ -361,6 +385,7 @@ struct SwdState {
     // period / mode bookkeeping
     int iq, k, ift, pass, ifirst;
     float t1a, t1b;
+    float pend;                       // value of an odd period waiting to be stored with the next one
     double omega, cprev, ck;
     // getsol / nevill
     int st, ev, idir, nev, nctrl, m, nbrk;
@@ -373,7 +398,7 @@ BH_DEV void swd_state_init(SwdState &S)
 {
     S.mmax = 1; S.llw = 1; S.err = 0; S.betmx = 0.f; S.cc = 0; S.cfail = 0;
     S.out = nullptr; S.cws = nullptr; S.cbws = nullptr;
-    S.iq = 1; S.k = 1; S.ift = 999; S.pass = 0; S.ifirst = 0; S.t1a = 0; S.t1b = 0;
+    S.iq = 1; S.k = 1; S.ift = 999; S.pass = 0; S.ifirst = 0; S.t1a = 0; S.t1b = 0; S.pend = 0;
     S.omega = 0; S.cprev = 0; S.ck = 0;
     S.st = SWD_ST_DONE; S.ev = SWD_EV_FETCH; S.idir = 1; S.nev = 1; S.nctrl = 1; S.m = 1; S.nbrk = 0;
     S.c1 = S.c2 = S.c3 = S.del1 = S.del2 = S.del3 = S.clow = S.del1st = S.ceval = 0;
@@ -495,10 +520,10 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
             }
             float cc0 = (float)S.ck, cc1b = (float)S.c1;
             if (igr == 0) {
-                S.out[S.k - 1] = (double)cc0;
+                swd_put(S.out, S.k, kmax, cc0, S.pend);
             } else {
                 float gvel = (1 / S.t1a - 1 / S.t1b) / (1 / (S.t1a * cc0) - 1 / (S.t1b * cc1b));
-                S.out[S.k - 1] = (double)gvel;
+                swd_put(S.out, S.k, kmax, gvel, S.pend);
             }
             S.cprev = S.ck;
             S.k++;
@@ -506,6 +531,7 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
         } else {                                      // NOROOT on the first solve: label 1700
             if (S.iq <= 1) S.err = 1;
             S.ift = S.k;
+            if (!(S.k & 1)) S.out[S.k - 2] = (double)S.pend;      // an odd period's value was still waiting
             for (int i = S.k; i <= kmax; i++) S.out[i - 1] = 0.0;
             S.iq++; S.k = 1;
             if (S.iq > nmode) { src.done(S.err); S.ev = SWD_EV_FETCH; }
