@@ -360,3 +360,53 @@ maxmodels = 50000
     files = sorted(os.listdir(str(tmp_path / 'results' / 'data')))
     assert 'st3_config.pkl' in files and sum(f.endswith('.npy') for f in files) == 30
     assert pool.nchains == 3 and list(pool.seeds) == [np.random.RandomState(5).randint(1000) for _ in range(1)] + list(pool.seeds[1:])
+
+
+def test_chain_pool_argument_errors(lib):
+    """Misuse of the bh_chains_* entry points is reported, not executed."""
+    from bayhunter_amd import _lib
+    ERR = _lib.BH_ERR_ARG
+    cfg = _lib.ChainConfig()
+    cfg.ntargets, cfg.layers_min, cfg.layers_max = 1, 1, 5
+    cfg.vs_min, cfg.vs_max, cfg.z_min, cfg.z_max = 2, 5, 0, 60
+    cfg.vpvs_fixed, cfg.vpvs_min, cfg.vpvs_max = 1, 1.73, 1.73
+    cfg.iter_burnin, cfg.iter_main = 5, 5
+    arrs = [np.full((2, 4, w), np.nan, dtype=np.float32) for w in (12, 2, 1, 2, 1)]
+    it = np.full((2, 4), np.nan)
+    st = _lib.ChainStorage()
+    st.nmodels = 4
+    for name, a in zip(('models', 'misfits', 'likes', 'noise', 'vpvs'), arrs):
+        setattr(st, name, a.ctypes.data)
+    st.iter = it.ctypes.data
+    seeds = np.array([1, 2], dtype=np.uint32)
+    h = C.c_void_p()
+
+    def create(c=cfg, n=2, s=st):
+        return lib.bh_chains_create(C.byref(c), n, seeds.ctypes.data, C.byref(s), C.byref(h))
+    assert create(n=0) == ERR
+    bad = _lib.ChainConfig.from_buffer_copy(cfg)
+    bad.ntargets = 0
+    assert create(c=bad) == ERR
+    bad = _lib.ChainConfig.from_buffer_copy(cfg)
+    bad.layers_max = 100                                   # more nuclei than NL = 100 layers
+    assert create(c=bad) == ERR and b'layer' in lib.bh_last_error()
+    bad = _lib.ChainConfig.from_buffer_copy(cfg)
+    bad.iter_main = -1
+    assert create(c=bad) == ERR
+    nost = _lib.ChainStorage()
+    nost.nmodels = 4
+    assert create(s=nost) == ERR and b'storage' in lib.bh_last_error()
+    assert create() == _lib.BH_OK
+    try:
+        assert lib.bh_chains_set_threads(h, 0) == ERR
+        assert lib.bh_chains_current(h, 2, None, None, None, None, None, None) == ERR
+        assert lib.bh_chains_current(h, 1, None, None, None, None, None, None) == _lib.BH_OK
+        out = np.zeros(3)
+        assert lib.bh_chains_draw(h, 0, 3, 0.0, 1.0, 3, out.ctypes.data) == ERR
+        assert lib.bh_chains_draw(h, 5, 0, 0.0, 1.0, 3, out.ctypes.data) == ERR
+        key = np.zeros(624, dtype=np.uint32)
+        assert lib.bh_chains_set_rng(h, 0, key.ctypes.data, 625, 0, 0.0) == ERR
+        assert lib.bh_chains_propose(h, 8, None, None, None, None, None) == ERR
+        assert lib.bh_chains_moves(h, None) == ERR and lib.bh_chains_accepted(h, None) == ERR
+    finally:
+        lib.bh_chains_destroy(h)
