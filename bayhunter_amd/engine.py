@@ -167,6 +167,10 @@ class ForwardEngine(object):
         models = H if isinstance(H, DeviceModels) else self.upload(H, VP, VS, RHO, nlay)
         if models.packed.device != self.device:
             raise ValueError("models live on %s, engine on %s" % (models.packed.device, self.device))
+        if models.order is None and self.sort_ragged and self.swd and models.B > ORDER_MIN:
+            # resident models that came without a processing order (e.g. models.layers_from_voronoi):
+            # computed once and kept with them
+            models.order = self.reorder(models.packed, models.nlay).order
         H, VP, VS, RHO, nlay = models.H, models.VP, models.VS, models.RHO, models.nlay
         B = models.B
         mstride = 4 * models.Lmax
