@@ -41,7 +41,7 @@ def gpu_backend(swd, rf):
     def run(H, VP, VS, RHO, nlay):
         out, err = eng.run(H, VP, VS, RHO, nlay)
         torch.cuda.synchronize()
-        return out.cpu().numpy(), err.cpu().numpy()
+        return out[:, :eng.ncols].cpu().numpy(), err.cpu().numpy()
     return run
 
 

@@ -51,10 +51,13 @@ class SwdSpec(object):
             raise ReferenceError("no dispersion forward model for ref '%s'" % ref)
         self.ref = ref
         self.iwave, self.igr = SWD_REFS[ref]
-        self.periods = np.ascontiguousarray(periods, dtype=np.float64)
-        if self.periods.size > _lib.MAX_PERIODS:
-            raise ValueError("at most 60 periods per call (surfdisp96.f:62); resample like "
-                             "SurfDisp does for longer vectors")
+        self.obsx = np.ascontiguousarray(periods, dtype=np.float64)
+        # more than NP = 60 periods (surfdisp96.f:62): solve on 60 evenly spaced periods over the same
+        # span and interpolate linearly to the observed ones, like SurfDisp (surf96_modsw.py:35-43,
+        # 106-122); ForwardEngine does the interpolation on the device
+        self.resample = self.obsx.size > _lib.MAX_PERIODS
+        self.periods = np.linspace(self.obsx.min(), self.obsx.max(), _lib.MAX_PERIODS) if self.resample \
+            else self.obsx
         self.mode, self.flsph = int(mode), int(flsph)
 
 
@@ -75,7 +78,10 @@ class RfSpec(object):
 class ForwardEngine(object):
     """All targets of a joint inversion for a batch of models in (at most) two launches.
 
-    Output row of model b: [swd target 0 | swd target 1 | ... | rf target 0 | ...], fp64.
+    Output row of model b: [swd target 0 | swd target 1 | ... | rf target 0 | ...], fp64, `ncols`
+    values; `slices[t]` is target t's column range.  Rows are `row` doubles apart: with a dispersion
+    target of more than 60 periods `row` > `ncols` (the 60 solved values live behind the visible
+    columns and are interpolated into them after the kernel).
     """
 
     def __init__(self, swd=(), rf=(), device=None):
@@ -89,25 +95,36 @@ class ForwardEngine(object):
         if len(self.swd) > _lib.MAX_TARGETS:
             raise ValueError("too many SWD targets")
         off = 0
+        self.slices = []
+        for sp in self.swd:
+            self.slices.append(slice(off, off + sp.obsx.size))
+            off += sp.obsx.size
+        rf_off = []
+        for r in self.rf:
+            rf_off.append(off)
+            self.slices.append(slice(off, off + r.obsx.size))
+            off += r.obsx.size
+        self.ncols = off
         per_off = 0
         self._tg = (_lib.SwdTarget * max(1, len(self.swd)))()
         pers = []
-        self.slices = []
-        for t, s in enumerate(self.swd):
-            self._tg[t] = _lib.SwdTarget(s.iwave, s.igr, s.mode, s.flsph, s.periods.size,
-                                         per_off, off, 0)
-            self.slices.append(slice(off, off + s.periods.size))
-            pers.append(s.periods)
-            off += s.periods.size
-            per_off += s.periods.size
+        self._interp = []                                  # (user slice, scratch offset, device tables)
+        for t, sp in enumerate(self.swd):
+            koff = self.slices[t].start
+            if sp.resample:                                # the kernel writes behind the visible columns
+                koff = off
+                off += sp.periods.size
+            self._tg[t] = _lib.SwdTarget(sp.iwave, sp.igr, sp.mode, sp.flsph, sp.periods.size,
+                                         per_off, koff, 0)
+            if sp.resample:
+                self._interp.append((self.slices[t], koff, self._interp_tables(sp)))
+            pers.append(sp.periods)
+            per_off += sp.periods.size
         self._rfp = []
-        for r in self.rf:
-            nout = r.obsx.size
+        for r, o in zip(self.rf, rf_off):
             self._rfp.append(_lib.RfParams(r.p, r.gauss, r.fsamp, r.tshft,
                                            -1.0 if r.nsv is None else float(r.nsv),
-                                           int(r.nsamp), r.waveno, nout, off))
-            self.slices.append(slice(off, off + nout))
-            off += nout
+                                           int(r.nsamp), r.waveno, r.obsx.size, o))
         self.row = off
         with torch.cuda.device(self.device):
             self.periods = torch.from_numpy(
@@ -119,6 +136,16 @@ class ForwardEngine(object):
         self.sort_ragged = True  # re-order ragged batches by layer count at upload
 
     # -- helpers
+    def _interp_tables(self, sp):
+        """numpy.interp(obsx, periods, values) as gather + two flops: left index j, x - xp[j],
+        xp[j+1] - xp[j], and which observed periods sit exactly on the last solved one."""
+        xp, x = sp.periods, sp.obsx
+        j = np.clip(np.searchsorted(xp, x, side='right') - 1, 0, xp.size - 2)
+        with torch.cuda.device(self.device):
+            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            return dict(j=dev(j.astype(np.int64)), xm=dev(x - xp[j]), dx=dev(xp[j + 1] - xp[j]),
+                        last=dev(x == xp[-1]), n=xp.size)
+
     def _as_dev(self, x, dtype):
         if isinstance(x, torch.Tensor):
             if x.device != self.device or x.dtype != dtype or not x.is_contiguous():
@@ -205,6 +232,12 @@ class ForwardEngine(object):
                     RHO.data_ptr(), len(self.swd), self._tg, self.periods.data_ptr(),
                     out.data_ptr(), self.row, err.data_ptr(),
                     models.order.data_ptr() if models.order is not None else None, ws_ptr, need, sp))
+                with torch.cuda.stream(st):
+                    for sl, koff, tb in self._interp:      # > 60 periods: numpy.interp on the device
+                        f = out[:, koff:koff + tb['n']]
+                        f0, f1 = f.index_select(1, tb['j']), f.index_select(1, tb['j'] + 1)
+                        y = ((f1 - f0) / tb['dx']) * tb['xm'] + f0
+                        out[:, sl] = torch.where(tb['last'], f[:, -1:].expand(-1, y.shape[1]), y)
             else:
                 err.zero_()
             rsp = sp if side is None else C.c_void_p(side.cuda_stream)

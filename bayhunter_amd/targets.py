@@ -243,8 +243,6 @@ class JointTarget(object):
         for t in self.targets:
             p = t.moddata.plugin
             if isinstance(p, SurfDisp):
-                if p.kmax > _lib.MAX_PERIODS:
-                    raise ValueError("evaluate_batch needs <= 60 periods per dispersion target")
                 order.append(('swd', len(swd)))
                 swd.append(SwdSpec(t.ref, p.obsx, p.modelparams['mode'], p.modelparams['flsph']))
             elif isinstance(p, RFminiModRF):

@@ -125,6 +125,45 @@ def test_rf_variants(lib, golden):
     print('rf variants worst |diff| = %.3e' % worst)
 
 
+def test_more_than_60_periods_in_the_batched_engine(lib):
+    """75 periods: the engine solves on 60 evenly spaced ones and interpolates on the device, which
+    must be SurfDisp.run_model's numpy.interp of the single-model solver, bit for bit; the fused
+    likelihood sees the interpolated columns."""
+    import torch
+    from bayhunter_amd import targets as T
+    from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
+    from bayhunter_amd.plugins import SurfDisp
+    per = np.sort(np.concatenate([np.linspace(1.0, 41.0, 60), np.linspace(1.3, 40.2, 15)]))   # some on the grid
+    H, VP, VS, RHO, nl = draw_models(40, (2, 9), seed=91, sorted_vs=False)
+    eng = ForwardEngine(swd=[SwdSpec('rdispph', per), SwdSpec('ldispgr', np.linspace(2, 30, 9))],
+                        rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
+    assert eng.ncols == 75 + 9 + 201 and eng.row == eng.ncols + 60
+    out, err = eng.run(H, VP, VS, RHO, nl)
+    out, err = out.cpu().numpy(), err.cpu().numpy()
+    plug = SurfDisp(per, 'rdispph')
+    for b in range(40):
+        n = nl[b]
+        x, y = plug.run_model(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n])
+        if err[b, 0]:
+            assert np.isnan(y) if np.isscalar(y) else False
+        else:
+            assert np.array_equal(x, per) and np.array_equal(out[b, eng.slices[0]], y), b
+    # through JointTarget.evaluate_batch against the one-model path
+    rs = np.random.RandomState(3)
+    t1 = T.RayleighDispersionPhase(per, 3.0 + 0.02 * per + 0.01 * rs.randn(75))
+    t2 = T.PReceiverFunction(np.linspace(-5, 35, 201), 0.05 * rs.randn(201))
+    joint = T.JointTarget([t1, t2])
+    joint.set_target_covariance([True, False], [0.0, 0.9])
+    noise = np.tile([0.0, 0.02, 0.85, 0.01], (40, 1))
+    logL, mis = joint.evaluate_batch(H, VP, VS, nl, noise)
+    logL, mis = logL.cpu().numpy(), mis.cpu().numpy()
+    for b in range(0, 40, 7):
+        n = nl[b]
+        joint.evaluate(h=H[b, :n], vp=VP[b, :n], vs=VS[b, :n], noise=noise[b])
+        assert np.isclose(joint.proposallikelihood, logL[b], rtol=1e-11, atol=1e-6)
+        assert np.allclose(joint.proposalmisfits, mis[b], rtol=1e-11)
+
+
 def test_batch_depth_hint_changes_nothing(lib):
     """Rows allocated for 31 layers holding models of at most 9: with the depth known the kernels
     size their LDS for 10 layers (and may pick another team width); values are the same bits."""
