@@ -77,7 +77,7 @@ def main():
     backend, nclients, niter, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     factory = gpu_backend if backend == 'gpu' else oracle_backend
     broker = ForwardBroker(swd=[('rdispph', PER)], rf=[('prf', TRF)], max_clients=nclients, Lmax=8,
-                           window=(2e-3 if backend == 'gpu' else 2e-2), backend_factory=factory).start()
+                           window=(2e-3 if backend == 'gpu' else 5e-3), backend_factory=factory).start()
     ctx = mp.get_context('fork')
     q = ctx.Queue()
     sessions = [broker.session() for _ in range(nclients)]
