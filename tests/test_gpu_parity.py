@@ -335,6 +335,32 @@ def test_full_size_properties(lib, oracle):
     assert np.abs(o[sl, eng.slices[4]] - oracle.rf_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl])).max() <= TOL_RF
 
 
+def test_headline_size_order_invariance(lib, oracle):
+    """The bench workload at its full size (524 288 ten-layer models, Rayleigh phase + P-RF): the
+    processing order (work queue in sorted order) changes no bit of any row, every model solves, and
+    a slice agrees with the oracle."""
+    import torch
+    from bayhunter_amd.engine import DeviceModels
+    B = 524288
+    per = np.linspace(1, 41, 21)
+    H, VP, VS, RHO, nl = draw_models(B, 10, seed=6000)
+    eng = _engine(['rdispph'], per, rf=True)
+    models = eng.upload(H, VP, VS, RHO, nl)
+    assert models.order is not None
+    out, err = eng.run(models)
+    eng.sort_ragged = False                                            # no order: queue in row order
+    out2, err2 = eng.run(DeviceModels(models.packed, models.nlay))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(err, err2)
+    assert int(err.sum().item()) == 0
+    del out2, err2
+    sl = slice(300000, 300064)
+    o = out[sl].cpu().numpy()
+    want, werr, _ = oracle.swd_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl], per, 2, 0)
+    assert np.array_equal(o[:, :21], want)                             # monotone models: bit-identical
+    assert np.abs(o[:, 21:] - oracle.rf_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl])).max() <= TOL_RF
+
+
 @pytest.fixture(params=['team', 'team32', 'team16', 'team8'])
 def team_mode(lib, request):
     from bayhunter_amd import _lib
