@@ -48,12 +48,10 @@ def csur(T):
     return 0.92 * (VS * w).sum(axis=1) / w.sum(axis=1)
 c1, c20, c41 = csur(1.0), csur(20.0), csur(41.0)
 keys = {
-    'S travel time': (tt,),
-    'surrogate c(41) - c(1)': (c41 - c1,),
-    'surrogate c(1) in 32 bins, then c(41)': (c41, bins(c1, 32)),
-    'surrogate c(41) in 32 bins, then c(1)': (c1, bins(c41, 32)),
-    'surrogate c(1) 16 bins, c(20) 16 bins, c(41)': (c41, bins(c20, 16), bins(c1, 16)),
+    'S travel time (ascending)': (tt,),
+    'S travel time (descending)': (-tt,),
     'travel time in 64 bins, then surrogate c(1)': (c1, bins(tt, 64)),
+    'travel time in 64 bins descending, then surrogate c(1)': (c1, -bins(tt, 64)),
 }
 for tag, ks in keys.items():
     o = np.lexsort(ks)
