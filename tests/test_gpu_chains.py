@@ -114,3 +114,48 @@ def test_gpu_pool_sharded_over_two_ranks(golden_chains):
         for k in ('models', 'noise', 'vpvs', 'iter'):
             assert np.array_equal(full[k][i, :n], golden_chains['constrained/%d/%s' % (seed, k)], equal_nan=True), (seed, k)
         assert np.allclose(full['likes'][i, :n], golden_chains['constrained/%d/likes' % seed], rtol=3e-7, atol=0)
+
+
+def test_hunt_script_on_the_gpu(tmp_path):
+    """tools/hunt.py with its default (GPU) evaluator: config.ini + data files -> result files, and
+    the same seeds give the same chains as a pool built by hand."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import hunt
+    ini = tmp_path / 'config.ini'
+    ini.write_text("""[modelpriors]
+vpvs = 1.4, 2.1
+layers = 1, 20
+vs = 2, 5
+z = 0, 60
+mohoest = None
+rfnoise_corr = 0.9
+swdnoise_corr = 0.
+rfnoise_sigma = 1e-5, 0.05
+swdnoise_sigma = 1e-5, 0.05
+
+[initparams]
+nchains = 6
+iter_burnin = 60
+iter_main = 30
+propdist = 0.015, 0.015, 0.015, 0.005, 0.005
+acceptance = 40, 45
+thickmin = 0.1
+lvz = None
+hvz = None
+rcond = 1e-5
+station = 'st3'
+savepath = '%s'
+maxmodels = 50000
+""" % str(tmp_path / 'out'))
+    pool = hunt.main([str(ini), '--target', 'rdispph=' + os.path.join(DATA, 'st3_rdispph.dat'),
+                      '--target', 'prf=' + os.path.join(DATA, 'st3_prf.dat'), '--seed', '11', '--full-storage'])
+    files = os.listdir(str(tmp_path / 'out' / 'data'))
+    assert 'st3_config.pkl' in files and sum(f.endswith('.npy') for f in files) == 60
+    from chain_scenario import joint_target
+    from bayhunter_amd.chains import ChainPool
+    priors, ip = hunt.load_params(str(ini))
+    ref = ChainPool(joint_target(DATA), initparams=ip, modelpriors=priors, seeds=[int(s) for s in pool.seeds],
+                    nmodels=91).run()
+    assert list(pool.seeds) == [np.random.RandomState(11).randint(1000)] + list(pool.seeds[1:])
+    for i in range(6):
+        assert np.array_equal(pool.chain(i)['models'], ref.chain(i)['models'], equal_nan=True)
