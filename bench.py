@@ -301,8 +301,10 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": dom_ms,
-                         "note": "fp64 scalar recurrence: the binding limit is FP64 VALU issue + "
-                                 "transcendental latency, see fp64_valu"},
+                         "binding_resource": "fp64_valu_issue",
+                         "binding_busy_frac": pmc.get('valu_busy'),
+                         "note": "fp64 scalar recurrence: neither HBM nor MFMA binds it; the VALU pipes "
+                                 "are busy binding_busy_frac of the dispatch (PMC, profiles/), see fp64_valu"},
             "fp64_valu": {"achieved": dom_flop / (dom_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
                           "unit": "TFLOP/s",
                           "frac": dom_flop / (dom_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
