@@ -15,11 +15,17 @@ SRC = [os.path.join(ROOT, 'tests', 'sanitize', 'chains_driver.cpp'),
 
 def _run(tmp_path, flags, threads, env=None):
     exe = str(tmp_path / ('driver_' + '_'.join(f.strip('-=').replace(',', '_') for f in flags)))
-    subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-pthread', '-ffp-contract=off'] + flags + SRC + ['-o', exe],
-                   check=True)
+    c = subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-pthread', '-ffp-contract=off'] + flags + SRC + ['-o', exe],
+                       capture_output=True, text=True)
+    if c.returncode != 0 and flags and ('cannot find' in c.stderr or 'sanitizer' in c.stderr.lower()):
+        pytest.skip('sanitizer runtime not installed: ' + c.stderr[-300:])
+    assert c.returncode == 0, c.stderr[-4000:]
     e = dict(os.environ, BH_CHAIN_SPIN_US='200')
     e.update(env or {})
     r = subprocess.run([exe, str(threads)], capture_output=True, text=True, timeout=600, env=e)
+    if flags and ('unexpected memory mapping' in r.stderr or 'Shadow memory range interleaves' in r.stderr
+                  or 'ReserveShadowMemoryRange failed' in r.stderr):
+        pytest.skip('the sanitizer runtime cannot start in this environment: ' + r.stderr[-300:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'runtime error' not in r.stderr and 'WARNING: ThreadSanitizer' not in r.stderr, r.stderr[-4000:]
     return [l for l in r.stdout.splitlines() if l.startswith('checksum')][0]
@@ -38,9 +44,14 @@ def test_device_solver_cores_under_asan_ubsan(tmp_path):
     models incl. 1 and 100 layers, water layer, LVZ, modes 1-3, 60 periods, four FFT lengths."""
     src = os.path.join(ROOT, 'tests', 'sanitize', 'cores_driver.cpp')
     exe = str(tmp_path / 'cores')
-    subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-ffp-contract=off', '-fsanitize=address,undefined',
-                    '-fno-omit-frame-pointer', src, '-o', exe], check=True)
+    c = subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-ffp-contract=off', '-fsanitize=address,undefined',
+                        '-fno-omit-frame-pointer', src, '-o', exe], capture_output=True, text=True)
+    if c.returncode != 0 and ('cannot find' in c.stderr or 'sanitizer' in c.stderr.lower()):
+        pytest.skip('sanitizer runtime not installed: ' + c.stderr[-300:])
+    assert c.returncode == 0, c.stderr[-4000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, UBSAN_OPTIONS='print_stacktrace=1'))
+    if 'Shadow memory range interleaves' in r.stderr or 'ReserveShadowMemoryRange failed' in r.stderr:
+        pytest.skip('the sanitizer runtime cannot start in this environment: ' + r.stderr[-300:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'cores ok' in r.stdout and 'runtime error' not in r.stderr, r.stderr[-4000:]
