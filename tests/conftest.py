@@ -126,7 +126,7 @@ def hostsim_devmath():
 @pytest.fixture(scope='session')
 def golden():
     return {name: np.load(os.path.join(GOLDEN, name + '.npz'))
-            for name in ('swd_rf_random', 'swd_variants', 'rf_variants', 'tutorial_full')}
+            for name in ('swd_rf_random', 'swd_variants', 'rf_variants', 'tutorial_full', 'swd_water')}
 
 
 @pytest.fixture(scope='session')

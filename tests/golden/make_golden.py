@@ -16,6 +16,9 @@ Files
   swd_variants.npz    modes 1..3, flsph 0/1, period counts 20/40/60 on a 10-layer set
   rf_variants.npz     P/SV x gauss x slowness x nsamp x nsv on a 10-layer set
   tutorial_full.npz   the tutorial model (st3) at full precision: 4 SWD targets, prf, srf
+  swd_water.npz       models under a water layer (vs[0] = 0 -> llw = 2, surfdisp96.f:134-135,
+                      :850-867), 5 and 10 layers, sorted and low-velocity-zone variants, the four
+                      dispersion targets (`python make_golden.py water` writes only this file)
 """
 import os
 import sys
@@ -31,8 +34,37 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 REFS = [('rdispph', 2, 0), ('rdispgr', 2, 1), ('ldispph', 1, 0), ('ldispgr', 1, 1)]
 
 
+def water_models(B, L, seed, sorted_vs):
+    """draw_models with the top layer turned into 0.3-4 km of water (vp 1.5, vs 0, rho 1.03)."""
+    H, VP, VS, RHO, nl = draw_models(B, L, seed=seed, sorted_vs=sorted_vs)
+    rs = np.random.RandomState(seed + 1)
+    H[:, 0] = rs.uniform(0.3, 4.0, size=B)
+    VP[:, 0], VS[:, 0], RHO[:, 0] = 1.5, 0.0, 1.03
+    return H, VP, VS, RHO, nl
+
+
+def make_water():
+    per = np.linspace(1, 41, 21)
+    d = {'periods': per}
+    k = 0
+    for L in (5, 10):
+        for srt in (True, False):
+            H, VP, VS, RHO, nl = water_models(24, L, 9400 + k, srt)
+            tag = 'L%d_%s' % (L, 'sorted' if srt else 'lvz')
+            d[tag + '_model'] = np.stack([H, VP, VS, RHO])
+            for name, iw, ig in REFS:
+                out, err, _ = po.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, backend='ref')
+                d[tag + '_' + name] = out
+                d[tag + '_' + name + '_err'] = err
+            k += 1
+    np.savez_compressed(os.path.join(OUT, 'swd_water.npz'), **d)
+
+
 def main():
     assert po.have_ref(), "oracle/_ref missing: run `make -C oracle ref` where /root/reference exists"
+    make_water()
+    if sys.argv[1:] == ['water']:
+        return
     per = np.linspace(1, 41, 21)
     d = {}
     k = 0

@@ -1,21 +1,16 @@
 """GPU tier (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden
 vectors.
 
-Tolerances (fp64 path).  Every IEEE operation of the search is replayed exactly; the only
-difference to the reference is the device libm (sin/cos/exp differ from glibc in the last bit).
-Measured on MI355X with tests/scenarios/parity_report.py (8 sets x 2048 models, profiles/parity_r01.txt):
-  * models with velocity increasing with depth (the tutorial, the bench workloads): all four
-    dispersion targets 100 % bit-identical
-  * models with low-velocity zones: the Rayleigh period equation is ill-conditioned near its root,
-    the last Neville/bisection iterate is then decided by rounding noise and lands anywhere inside
-    the reference's own stopping bracket |c1-c2| <= 1e-6*c1 (surfdisp96.f:614):
-      phase velocity  : >= 99 % of values bit-identical, |diff| <= 1.5e-6 * c   (observed 1.04e-6)
-      group velocity  : fp32 finite difference of two roots, amplifies by 1/(2h) = 100:
-                        ~99 % bit-identical (>= 97 % asserted per 24-model set), |diff| <= 1.5e-3                (observed 6.5e-4)
-  * err flags         : identical
-  * receiver function : |diff| <= 1e-10 (observed <= 3.5e-13 at amplitudes up to 5.6)
-  * north_star        : RMS misfit against the tutorial dataset within 1e-6 of the reference's
-                        (TOL_MISFIT, test_tutorial_dataset_single_model_dropins)
+Tolerances: tests/tolerances.py (derived from the reference's own stopping criterion, with the
+evidence that the reference differs from itself by as much when only glibc's libm variant changes,
+profiles/r02_libm_selfdiff.txt).  In short:
+  * velocity increasing with depth (tutorial, bench workloads): dispersion bit-identical
+  * low-velocity zones: Rayleigh phase |dc|/c <= 1.2e-6, group |dU|/U <= 2.5e-4, >= 99 % of the
+    values bit-identical on large sets; Love bit-identical
+  * err flags identical; receiver function |diff| <= 1e-10
+  * north_star: RMS misfit against the tutorial dataset within 1e-6 of the reference's
+The large-sample campaigns (131 072 bench models, 2 048-model LVZ sets, exact BASELINE shapes, water
+layer) are in tests/test_gpu_campaign.py.
 """
 import os
 
@@ -27,11 +22,8 @@ from conftest import GOLDEN, REFS, SETS
 
 pytestmark = pytest.mark.gpu
 
-TOL_PHASE_REL = 1.5e-6   # relative to c: the reference's convergence slack
-TOL_PHASE = 1.5e-6 * 5.0  # absolute bound for c <= 5 km/s
-TOL_GROUP = 1.5e-3
-TOL_RF = 1.0e-10
-TOL_MISFIT = 1.0e-6
+from tolerances import (MIN_IDENTICAL_LVZ_SMALL, MIN_IDENTICAL_MONOTONE, TOL_GROUP, TOL_GROUP_REL,
+                        TOL_MISFIT, TOL_PHASE, TOL_PHASE_REL, TOL_RF)
 
 
 def _nlay(model):
@@ -44,19 +36,23 @@ def _engine(refs, per, rf=False, **kw):
                          rf=[RfSpec('prf', np.linspace(-5, 35, 201))] if rf else [])
 
 
-def _check_swd(name, got, want, err_got, err_want, monotone=False):
+def _check_swd(name, got, want, err_got, err_want, monotone=False, min_identical=MIN_IDENTICAL_LVZ_SMALL):
+    """err flags equal; solved rows within the derived bounds (tolerances.py); Love and monotone
+    models bit-identical; zero-filled tails (failed searches) identical."""
     assert np.array_equal(err_got, err_want), name
-    ok = err_want == 0
+    bad = err_want != 0
+    assert np.array_equal(got[bad], want[bad]), name             # zero fill from the failing period on
+    ok = ~bad
     got, want = got[ok], want[ok]
-    d = np.abs(got - want)
+    if got.size == 0:
+        return 1.0
     frac = float((got == want).mean())
-    if name.endswith('gr'):
-        assert d.max() <= TOL_GROUP, (name, d.max())
-        assert frac >= (0.999 if monotone else 0.97), (name, frac)
-    else:
-        assert (d / want).max() <= TOL_PHASE_REL, (name, (d / want).max())
-        assert frac >= (0.999 if monotone else 0.99), (name, frac)
-    assert np.array_equal(got[:0], want[:0])
+    if monotone or name.startswith('l'):
+        assert frac >= MIN_IDENTICAL_MONOTONE, (name, frac)
+        return frac
+    rel = np.abs(got - want) / np.abs(want)
+    assert rel.max() <= (TOL_GROUP_REL if name.endswith('gr') else TOL_PHASE_REL), (name, rel.max())
+    assert frac >= min_identical, (name, frac)
     return frac
 
 
@@ -222,7 +218,7 @@ def test_tutorial_dataset_single_model_dropins(lib, golden):
         obs = np.loadtxt(os.path.join(GOLDEN, 'tutorial_observed', 'st3_%s.dat' % name))
         x, y = bh.SurfDisp(per, name).run_model(h, vp, vs, rho)
         assert np.array_equal(x, per)
-        assert np.abs(y - full[name]).max() <= (TOL_GROUP if name.endswith('gr') else TOL_PHASE)
+        assert np.array_equal(y, full[name]), name                   # the tutorial model: bit-identical
         mis_ref = np.sqrt(np.mean((full[name] - obs[:, 1]) ** 2))
         mis_gpu = np.sqrt(np.mean((y - obs[:, 1]) ** 2))
         assert abs(mis_ref - mis_gpu) <= TOL_MISFIT

@@ -128,3 +128,64 @@ def test_live_against_reference(oracle):
         a = oracle.rf_batch(H, VP, VS, RHO, nl, waveno=wn, backend='port')
         r = oracle.rf_batch(H, VP, VS, RHO, nl, waveno=wn, backend='ref')
         assert np.array_equal(a, r, equal_nan=True)
+
+
+@pytest.mark.parametrize('tag', ['L5_sorted', 'L5_lvz', 'L10_sorted', 'L10_lvz'])
+def test_swd_water_layer_golden_bitexact(oracle, golden, tag):
+    """vs[0] = 0: llw = 2 and the water-layer tail of dltar4 (surfdisp96.f:134-135, :850-867);
+    goldens from the reference binary (tests/golden/make_golden.py water)."""
+    g = golden['swd_water']
+    H, VP, VS, RHO = g[tag + '_model']
+    assert np.all(VS[:, 0] == 0.0)
+    nl = np.array([1 + int((m[1:] > 0).sum()) for m in VS], dtype=np.int32)
+    for name, iw, ig in REFS:
+        out, err, _ = oracle.swd_batch(H, VP, VS, RHO, nl, g['periods'], iw, ig)
+        assert np.array_equal(err, g[tag + '_' + name + '_err']), name
+        assert np.array_equal(out, g[tag + '_' + name]), name
+
+
+def test_reference_differs_from_itself_by_the_stated_tolerances(oracle):
+    """The low-velocity-zone tolerances of the GPU tier (tests/tolerances.py) are the reference's own
+    reproducibility across libm builds: run the oracle under glibc's non-FMA sin/cos/exp
+    (GLIBC_TUNABLES) in a child process and compare with this process's (FMA) results.  The full
+    table, taken with the reference binary itself, is profiles/r02_libm_selfdiff.txt."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from tolerances import TOL_GROUP_REL, TOL_PHASE_REL
+    cpu = open('/proc/cpuinfo').read()
+    if not (' fma ' in cpu and ' avx2 ' in cpu):
+        pytest.skip('host CPU has no FMA: glibc has only one libm variant to offer here')
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import pyoracle as po
+from bayhunter_amd.synthetic import draw_models
+H, VP, VS, RHO, nl = draw_models(768, 10, seed=4263, sorted_vs=False)
+per = np.linspace(1, 41, 21)
+r = {}
+for name, iw, ig in (('ph', 2, 0), ('gr', 2, 1), ('lph', 1, 0)):
+    r[name], r[name + '_err'], _ = po.swd_batch(H, VP, VS, RHO, nl, per, iw, ig, nthreads=8)
+np.savez(sys.argv[1], **r)
+""" % ROOT
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for i, tun in enumerate(('', 'glibc.cpu.hwcaps=-FMA,-AVX2,-FMA4')):
+            env = dict(os.environ)
+            env.pop('GLIBC_TUNABLES', None)
+            if tun:
+                env['GLIBC_TUNABLES'] = tun
+            path = os.path.join(td, '%d.npz' % i)
+            subprocess.run([sys.executable, '-c', code, path], check=True, env=env)
+            with np.load(path) as z:
+                res.append({k: z[k] for k in z.files})
+    a, b = res
+    for name, tol in (('ph', TOL_PHASE_REL), ('gr', TOL_GROUP_REL)):
+        assert np.array_equal(a[name + '_err'], b[name + '_err'])
+        ok = a[name + '_err'] == 0
+        rel = np.abs(a[name][ok] - b[name][ok]) / np.abs(a[name][ok])
+        assert rel.max() <= tol, (name, rel.max())                # within the derived bound ...
+        assert rel.max() > 0.05 * tol, (name, rel.max())          # ... and of its order: not bit-identical
+        assert (rel == 0).mean() >= 0.99
+    assert np.array_equal(a['lph'], b['lph'])                     # Love: well conditioned, identical
