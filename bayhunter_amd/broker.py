@@ -25,7 +25,10 @@ compute back end is a factory called inside the server process: the default buil
 ForwardEngine (GPU, no CPU fallback); tests inject their own.
 """
 import multiprocessing as mp
+import os
+import sys
 import time
+import traceback
 
 import numpy as np
 
@@ -45,9 +48,37 @@ def gpu_backend(swd, rf):
     return run
 
 
+class BrokerError(RuntimeError):
+    """The broker's server process failed or is gone; the chain cannot be evaluated any further."""
+
+
+def _fail(S, text):
+    """Server side: publish the failure and wake every client that is (or will be) waiting."""
+    raw = text.encode('utf-8', 'replace')[-(len(S['errtext']) - 1):]
+    S['errtext'][:len(raw)] = raw
+    S['failed'].value = 1
+    S['ready'].release()
+    for sem in S['done']:
+        sem.release()
+
+
+def _server_alive(pid):
+    """Is process `pid` running?  (A child that died but was not reaped yet is a zombie: not alive.)"""
+    try:
+        with open('/proc/%d/stat' % pid) as f:
+            return f.read().rsplit(')', 1)[1].split()[0] not in ('Z', 'X')
+    except (IOError, OSError, IndexError):
+        return False
+
+
 def _serve(shared, backend_factory, swd, rf):
-    run = backend_factory(swd, rf)
     S = shared
+    S['server_pid'].value = os.getpid()
+    try:
+        run = backend_factory(swd, rf)
+    except BaseException:
+        _fail(S, 'broker back end could not be created:\n' + traceback.format_exc())
+        return
     model = np.frombuffer(S['model'], dtype=np.float64).reshape(S['n'], 4, S['Lmax'])
     rows = np.frombuffer(S['rows'], dtype=np.float64).reshape(S['n'], S['row'])
     flags = np.frombuffer(S['flags'], dtype=np.int32).reshape(S['n'], S['nflags'])
@@ -72,9 +103,16 @@ def _serve(shared, backend_factory, swd, rf):
             continue
         t0 = time.perf_counter()
         m = model[pending]
-        out, err = run(m[:, 0], m[:, 1], m[:, 2], m[:, 3], nlay[pending].copy())
-        rows[pending] = out
-        flags[pending] = err
+        try:
+            out, err = run(m[:, 0], m[:, 1], m[:, 2], m[:, 3], nlay[pending].copy())
+            rows[pending] = out
+            flags[pending] = err
+        except BaseException:
+            # A failed launch (HIP error, out of memory, bad shapes) ends the server: a process that
+            # has touched the GPU is never restarted in place.  Clients raise BrokerError; recovery
+            # is a fresh ForwardBroker started from a process that has not used the GPU.
+            _fail(S, 'broker launch of %d models failed:\n' % pending.size + traceback.format_exc())
+            return
         stats[0] += 1
         stats[1] += pending.size
         stats[2] += time.perf_counter() - t0
@@ -105,18 +143,33 @@ class ForwardBroker(object):
             flags=ctx.RawArray('i', n * max(1, len(self.swd))), nlay=ctx.RawArray('i', n),
             state=ctx.RawArray('i', n), stats=ctx.RawArray('d', 3),
             wake=ctx.Semaphore(0), ready=ctx.Semaphore(0), done=[ctx.Semaphore(0) for _ in range(n)],
-            connected=ctx.Value('i', 0), stop=ctx.Value('i', 0), next_slot=ctx.Value('i', 0))
+            connected=ctx.Value('i', 0), stop=ctx.Value('i', 0), next_slot=ctx.Value('i', 0),
+            failed=ctx.Value('i', 0), server_pid=ctx.Value('i', 0), errtext=ctx.RawArray('c', 4096))
         self._factory = backend_factory
         self._proc = None
 
     def start(self):
-        """Fork the server (before anything in this process touches the GPU)."""
+        """Fork the server.  Nothing in this process may have touched the GPU before: a forked child
+        inherits a HIP runtime it cannot use (first launch faults or hangs)."""
+        torch = sys.modules.get('torch')
+        if self._factory is gpu_backend and torch is not None and torch.cuda.is_initialized():
+            raise BrokerError("ForwardBroker.start() after this process initialised the GPU: start the "
+                              "broker first (or from a fresh process), then create engines / chain pools")
         self._proc = self._ctx.Process(target=_serve, args=(self.shared, self._factory, self.swd, self.rf),
                                        daemon=True)
         self._proc.start()
         if not self.shared['ready'].acquire(timeout=300):
-            raise RuntimeError("broker server did not come up")
+            raise BrokerError("broker server did not come up")
+        if self.shared['failed'].value:
+            raise BrokerError(self.error())
         return self
+
+    def error(self):
+        """The server's failure report ('' while it is healthy)."""
+        return bytes(self.shared['errtext'][:]).split(b'\0', 1)[0].decode('utf-8', 'replace')
+
+    def alive(self):
+        return self._proc is not None and self._proc.is_alive() and not self.shared['failed'].value
 
     def session(self):
         """A handle for one chain; create it in the parent (or the chain) process, use it in one."""
@@ -151,6 +204,7 @@ class BrokerSession(object):
         self._row = None
         self._flags = None
         self._open = False
+        self.poll = 0.5          # seconds between liveness checks while waiting for a launch
 
     def _views(self):
         S = self.S
@@ -192,7 +246,15 @@ class BrokerSession(object):
         nlay[self.slot] = n
         state[self.slot] = REQUEST
         self.S['wake'].release()
-        self.S['done'][self.slot].acquire()
+        # never wait blindly: if the server died (HIP error, OOM kill, ...) this chain must end with
+        # an error, not hang -- the reference's mp_inversion would wait for it forever
+        while not self.S['done'][self.slot].acquire(timeout=self.poll):
+            if self.S['failed'].value or not _server_alive(self.S['server_pid'].value):
+                break
+        if self.S['failed'].value or state[self.slot] != DONE:
+            state[self.slot] = IDLE
+            text = bytes(self.S['errtext'][:]).split(b'\0', 1)[0].decode('utf-8', 'replace')
+            raise BrokerError(text or "the broker's server process is gone (killed?)")
         state[self.slot] = IDLE
         self._key, self._row, self._flags = key, rows[self.slot].copy(), flags[self.slot].copy()
         return self._row, self._flags

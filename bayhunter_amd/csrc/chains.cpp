@@ -191,9 +191,15 @@ public:
             for (int i = 0; i < nitems; i++) f(i);
             return;
         }
+        // A worker created now must only react to jobs published after its creation: it starts
+        // with the current generation as "seen" (gen_ only changes in this function and in the
+        // destructor, so the value cannot move between the load and the thread's first poll).
+        // Starting at 0 let a late-created worker fall through its wait loop, read the job fields
+        // while they were being written below and acknowledge a job it was never counted for.
+        const long g0 = gen_.load();
         while ((int)th_.size() < parts - 1) {
             int id = (int)th_.size() + 1;
-            th_.emplace_back([this, id]() { loop(id); });
+            th_.emplace_back([this, id, g0]() { loop(id, g0); });
         }
         // every worker acknowledges every job, also those it has no block in: the job fields below
         // are never rewritten while a straggler could still be reading them
@@ -221,9 +227,8 @@ private:
         int lo = id * per, hi = std::min(nitems_, lo + per);
         for (int i = lo; i < hi; i++) (*f_)(i);
     }
-    void loop(int id)
+    void loop(int id, long seen)
     {
-        long seen = 0;
         for (;;) {
             auto t0 = std::chrono::steady_clock::now();
             int polls = 0;

@@ -79,12 +79,17 @@ struct Pool {
 int main(int argc, char **argv)
 {
     int threads = argc > 1 ? std::atoi(argv[1]) : 8;
+    // "ascending": the smallest pool steps first, so the helper-thread set GROWS after the first
+    // job has been published (a worker created then must not react to the earlier generations)
+    const bool ascending = argc > 2 && std::string(argv[2]) == "ascending";
     Pool a(3000, 60), b(700, 40), c(130, 90);        // 8-, 5- and 1-part jobs interleave
     for (Pool *q : {&a, &b, &c}) bh_chains_set_threads(q->p, threads);
+    std::vector<Pool *> order = {&a, &b, &c};
+    if (ascending) order = {&c, &b, &a};
     bool more = true;
     while (more) {
         more = false;
-        for (Pool *q : {&a, &b, &c}) more = q->step() || more;
+        for (Pool *q : order) more = q->step() || more;
     }
     std::printf("checksum %.6f %.6f %.6f\n", a.checksum(), b.checksum(), c.checksum());
     return 0;

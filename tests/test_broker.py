@@ -74,3 +74,79 @@ def test_broker_on_gpu(oracle, tmp_path):
     assert np.array_equal(got['likes'] == -1e15, fail)
     assert np.allclose(got['likes'][~fail], want[~fail], rtol=1e-6)
     assert got['mean_batch'] > 4.0
+
+
+# ---- server failure: clients must raise, never hang --------------------------------------------
+def _flaky_backend(swd, rf):
+    """Injected back end: a valid row for the first launch, an exception on the second."""
+    calls = [0]
+
+    def run(H, VP, VS, RHO, nlay):
+        calls[0] += 1
+        if calls[0] >= 2:
+            raise RuntimeError('simulated HIP error in launch %d' % calls[0])
+        return np.full((H.shape[0], 3), 7.0), np.zeros((H.shape[0], 1), dtype=np.int32)
+    return run
+
+
+def _suicidal_backend(swd, rf):
+    def run(H, VP, VS, RHO, nlay):
+        os._exit(9)                       # what an OOM kill or a GPU fault looks like from outside
+    return run
+
+
+def _broken_factory(swd, rf):
+    raise RuntimeError('no usable device')
+
+
+def _client(sess, q):
+    from bayhunter_amd.broker import BrokerError
+    sess.poll = 0.05
+    h = np.array([5., 0.])
+    try:
+        for i in range(3):
+            row, _ = sess.evaluate(h + i, h * 0 + 6, h * 0 + 3.5, h * 0 + 2.7)
+            q.put(('ok', float(row[0])))
+    except BrokerError as e:
+        q.put(('err', str(e)))
+
+
+def _drive(factory):
+    import multiprocessing as mp
+    from bayhunter_amd.broker import ForwardBroker
+    br = ForwardBroker(swd=[('rdispph', np.array([1., 2., 3.]))], max_clients=4, Lmax=4,
+                       backend_factory=factory).start()
+    ctx = mp.get_context('fork')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_client, args=(br.session(), q)) for _ in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=60)
+        assert not p.is_alive(), 'client hung after the server failed'
+    msgs = []
+    while not q.empty():
+        msgs.append(q.get())
+    alive = br.alive()
+    br.stop()
+    return msgs, alive, br
+
+
+def test_clients_raise_when_a_launch_fails():
+    msgs, alive, br = _drive(_flaky_backend)
+    errs = [m for m in msgs if m[0] == 'err']
+    assert len(errs) == 2 and all('simulated HIP error' in m[1] for m in errs)
+    assert not alive and 'simulated HIP error' in br.error()
+
+
+def test_clients_raise_when_the_server_is_killed():
+    msgs, alive, _ = _drive(_suicidal_backend)
+    errs = [m for m in msgs if m[0] == 'err']
+    assert len(errs) == 2 and all('gone' in m[1] for m in errs)
+    assert not alive
+
+
+def test_start_reports_a_back_end_that_cannot_be_created():
+    from bayhunter_amd.broker import BrokerError, ForwardBroker
+    with pytest.raises(BrokerError, match='no usable device'):
+        ForwardBroker(swd=[('rdispph', np.array([1., 2., 3.]))], backend_factory=_broken_factory).start()
