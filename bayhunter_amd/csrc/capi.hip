@@ -1,5 +1,6 @@
 // capi.hip -- the C ABI of libbayhunter_amd.so (include/bayhunter_amd.h).  Host code only.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
@@ -76,37 +77,94 @@ int get_twiddles(int nsamp, const double **out)
     return BH_OK;
 }
 
-// Work-queue heads for swd_kernel: a ring of slots per device so that launches in flight on
-// different streams never share a counter; each launch zeroes its slot on its own stream.
+// Work-queue heads for the dispersion kernels: a ring of slots per device so that launches in flight
+// on different streams never share a counter; each launch zeroes its slot on its own stream.  A slot
+// is handed out again only when the launch that used it last has finished: every slot carries an
+// event recorded behind its launch (release_queue_slot), and a slot whose event is still pending is
+// waited for -- with more launches in flight than slots the caller blocks instead of two kernels
+// sharing (and corrupting) one counter.  BH_SWD_QUEUE_SLOTS shrinks the ring (test hook).
 constexpr int kQueueSlots = 256;
 struct DevState {
     unsigned int *queue = nullptr;
     unsigned long next = 0;
-    int cus = 0;
+    int cus = 0, nslots = kQueueSlots;
+    hipEvent_t done[kQueueSlots];
+    bool used[kQueueSlots];
+    bool claimed[kQueueSlots];        // taken by a host thread that has not recorded its event yet
+    unsigned long waits = 0;          // how often a launch had to wait for its slot (diagnostic)
 };
 std::mutex g_dev_mutex;
 std::map<int, DevState> g_dev;
 
-int get_queue_slot(unsigned int **slot, int *resident_waves)
+int get_queue_slot(unsigned int **slot, int *slot_index, int *resident_waves)
 {
     int dev = 0;
     BH_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    std::unique_lock<std::mutex> lock(g_dev_mutex);
     DevState &d = g_dev[dev];
     if (!d.queue) {
         BH_HIP(hipMalloc((void **)&d.queue, (size_t)kQueueSlots * bh::BH_NT * sizeof(unsigned int)));
         hipDeviceProp_t prop;
         BH_HIP(hipGetDeviceProperties(&prop, dev));
         d.cus = prop.multiProcessorCount;
+        for (int i = 0; i < kQueueSlots; i++) d.used[i] = d.claimed[i] = false;
+        if (const char *e = std::getenv("BH_SWD_QUEUE_SLOTS")) {
+            int v = std::atoi(e);
+            if (v >= 1 && v <= kQueueSlots) d.nslots = v;
+        }
     }
-    *slot = d.queue + (size_t)(d.next++ % kQueueSlots) * bh::BH_NT;
+    int i = (int)(d.next++ % (unsigned long)d.nslots);
+    for (int tries = 0; d.claimed[i]; tries++) {       // another thread is between get and release
+        if (tries >= d.nslots) {
+            g_err = "all work-queue slots are claimed by concurrent launches";
+            return BH_ERR_WORKSPACE;
+        }
+        i = (int)(d.next++ % (unsigned long)d.nslots);
+    }
+    d.claimed[i] = true;
+    if (d.used[i]) {
+        hipError_t q = hipEventQuery(d.done[i]);
+        if (q == hipErrorNotReady) {
+            d.waits++;
+            hipEvent_t ev = d.done[i];
+            // the ring is full of launches in flight: wait for the oldest one.  Slot i stays ours
+            // (next has moved on), so the mutex need not be held while waiting.
+            lock.unlock();
+            hipError_t we = hipEventSynchronize(ev);
+            lock.lock();
+            if (we != hipSuccess) { d.claimed[i] = false; return fail_hip(we, "hipEventSynchronize(queue slot)"); }
+        } else if (q != hipSuccess) {
+            d.claimed[i] = false;
+            return fail_hip(q, "hipEventQuery(queue slot)");
+        }
+    } else {
+        hipError_t ce = hipEventCreateWithFlags(&d.done[i], hipEventDisableTiming);
+        if (ce != hipSuccess) { d.claimed[i] = false; return fail_hip(ce, "hipEventCreate(queue slot)"); }
+        d.used[i] = true;
+    }
+    *slot = d.queue + (size_t)i * bh::BH_NT;
+    *slot_index = i;
     *resident_waves = d.cus * 8;   // 2 waves/SIMD x 4 SIMDs (VGPR-limited, kernels.hip)
     static const char *e = std::getenv("BH_SWD_RESIDENT_WAVES");   // test hook: forces the queue path
     if (e && std::atoi(e) > 0) *resident_waves = std::atoi(e);
     return BH_OK;
 }
 
-int g_swd_mode = BH_SWD_AUTO;
+// marks the end of the launch that used slot `i` on `stream`
+int release_queue_slot(int i, hipStream_t stream)
+{
+    int dev = 0;
+    BH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    DevState &d = g_dev[dev];
+    hipError_t e = hipEventRecord(d.done[i], stream);
+    d.claimed[i] = false;
+    if (e != hipSuccess) return fail_hip(e, "hipEventRecord(queue slot)");
+    return BH_OK;
+}
+
+// kernel choice of bh_swd_batch: process-wide default (bh_swd_set_kernel), read once per call
+std::atomic<int> g_swd_mode{BH_SWD_AUTO};
 
 long team_threshold()
 {
@@ -154,7 +212,7 @@ int bh_set_device(int device)
 int bh_swd_set_kernel(int mode)
 {
     if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM8) return fail_arg("unknown kernel mode");
-    g_swd_mode = mode;
+    g_swd_mode.store(mode, std::memory_order_relaxed);
     return BH_OK;
 }
 
@@ -210,9 +268,10 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     A.out = out; A.err = err; A.ws = (double *)workspace;
     A.vec2 = (Lmax % 2 == 0 && model_stride % 2 == 0 &&
               (((uintptr_t)h | (uintptr_t)vp | (uintptr_t)vs | (uintptr_t)rho) & 15) == 0) ? 1 : 0;
-    int resident = 0;
-    rc = get_queue_slot(&A.counters, &resident);
+    int resident = 0, slot = 0;
+    rc = get_queue_slot(&A.counters, &slot, &resident);
     if (rc) return rc;
+    const int swd_mode = g_swd_mode.load(std::memory_order_relaxed);
     // Few searches: spend a whole wave on each (swd_team.h, ~10x lower latency); many: one lane
     // each (swd_lane, ~5x more searches per second).  bh_swd_set_kernel overrides.
     // Which kernel: a small cost model fitted to profiles/r01_team_widths.txt (3-15 layers).  A team
@@ -247,16 +306,18 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
             if (cost < best) { best = cost; team = true; width = widths[i]; team_resident = (int)waves_of[i]; }
         }
     }
-    if (g_swd_mode == BH_SWD_LANE) team = false;
-    if (g_swd_mode >= BH_SWD_TEAM) {
+    if (swd_mode == BH_SWD_LANE) team = false;
+    if (swd_mode >= BH_SWD_TEAM) {
         team = true;
-        const int i = g_swd_mode == BH_SWD_TEAM8 ? 3 : g_swd_mode == BH_SWD_TEAM16 ? 2 : g_swd_mode == BH_SWD_TEAM32 ? 1 : 0;
+        const int i = swd_mode == BH_SWD_TEAM8 ? 3 : swd_mode == BH_SWD_TEAM16 ? 2 : swd_mode == BH_SWD_TEAM32 ? 1 : 0;
         width = widths[i];
         team_resident = waves_of[i] > 0 ? (int)waves_of[i] : 1;
     }
-    if (team) BH_HIP(bh::launch_swd_team(A, width, team_resident, (hipStream_t)stream));
-    else BH_HIP(bh::launch_swd(A, resident, (hipStream_t)stream));
-    return BH_OK;
+    hipError_t le = team ? bh::launch_swd_team(A, width, team_resident, (hipStream_t)stream)
+                         : bh::launch_swd(A, resident, (hipStream_t)stream);
+    rc = release_queue_slot(slot, (hipStream_t)stream);    // also after a failed launch: the slot is free
+    if (le != hipSuccess) return fail_hip(le, "dispersion kernel launch");
+    return rc;
 }
 
 size_t bh_rf_workspace_bytes(int, int, const bh_rf_params *) { return 0; }

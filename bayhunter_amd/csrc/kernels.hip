@@ -177,6 +177,24 @@ struct TeamSrc {
 // one from the per-target work queue (so ragged batches do not leave teams idle next to a deep
 // model) and idles only when the queue is empty.  (__syncthreads in a one-wave workgroup is an LDS
 // fence, also under divergence.)
+// Diagnostic build only (-DBH_TEAM_PROFILE, tools/team_phase_profile.py): shader-clock cycles per
+// phase of the 64-lane team loop, summed over all searches; read back with bh_debug_team_profile.
+#if defined(BH_TEAM_PROFILE)
+__device__ unsigned long long g_team_prof[8];
+#define BH_TP_DECL unsigned long long tp_[6] = {0, 0, 0, 0, 0, 0}, tp_t0_ = clock64(), tp_t1_
+#define BH_TP(i) (tp_t1_ = clock64(), tp_[i] += tp_t1_ - tp_t0_, tp_t0_ = tp_t1_)
+#define BH_TP_FLUSH(rounds)                                                                  \
+    if (threadIdx.x == 0) {                                                                  \
+        for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_team_prof[i_], tp_[i_]);                 \
+        atomicAdd(&g_team_prof[6], (unsigned long long)(rounds));                            \
+        atomicAdd(&g_team_prof[7], 1ull);                                                    \
+    }
+#else
+#define BH_TP_DECL
+#define BH_TP(i)
+#define BH_TP_FLUSH(rounds)
+#endif
+
 template <int TEAM>
 __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
 {
@@ -195,19 +213,29 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
     SwdState S;
     swd_state_init(S);
     if constexpr (NSUB == 1) {
+        BH_TP_DECL;
+        long rounds = 0;
         for (;;) {
             swd_driver(S, lay, src, tg, per, A.B);
             if (S.st == SWD_ST_DONE) break;
+            BH_TP(0);
             const int nt = swd_team_plan(S, TEAM, trials);
             __syncthreads();
+            BH_TP(1);
             swd_team_assemble(lay, lane, TEAM, tg.iwave, S, nt, trials, mats);
             __syncthreads();
+            BH_TP(2);
             if (tg.iwave == 2 && nt <= 8) swd_team_chain_ray5(lay, lane, S, nt, trials, mats, dels);
             else swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
             __syncthreads();
+            BH_TP(3);
             swd_team_consume(S, nt, trials, dels);
             __syncthreads();
+            BH_TP(4);
+            rounds++;
         }
+        BH_TP_FLUSH(rounds);
+        (void)rounds;
     } else {
         // A team whose search is over keeps walking through the phases with nt = 0 (no trial, no
         // matrix, no value consumed): cheaper than predicating every phase on a per-team flag.
@@ -365,6 +393,18 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         }
     }
 }
+
+#if defined(BH_TEAM_PROFILE)
+extern "C" int bh_debug_team_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_team_prof), sizeof(g_team_prof)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_team_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------- launch
 // LDS of one wave of the team kernel with `team` lanes per search

@@ -204,10 +204,15 @@ class ForwardEngine(object):
         Lmax = models.Lmax
         if models.depth is not None:                 # even, so that rows can be fetched two layers at a time
             Lmax = min(models.Lmax, models.depth + (models.depth % 2))
-        if out is None or err is None:
-            out, err = self.alloc_out(B)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         sp = C.c_void_p(st.cuda_stream)
+        if out is None or err is None:
+            # allocated on the launch stream (the caching allocator recycles a block for the stream
+            # it was allocated on); a buffer the caller passed is kept, only the missing one is made
+            with torch.cuda.stream(st):
+                new_out, new_err = self.alloc_out(B)
+            out = new_out if out is None else out
+            err = new_err if err is None else err
         with torch.cuda.device(self.device):
             # The two kernels are independent.  swd_kernel ends with a tail in which its persistent
             # waves retire one by one; launched on a second stream, rf_kernel's workgroups take over
@@ -224,8 +229,9 @@ class ForwardEngine(object):
                 if need:
                     ws = self._ws.get(st.cuda_stream)
                     if ws is None or ws.numel() * 8 < need:
-                        ws = self._ws[st.cuda_stream] = torch.empty((need + 7) // 8, dtype=torch.float64,
-                                                                    device=self.device)
+                        with torch.cuda.stream(st):      # the old block returns to this stream's pool
+                            ws = self._ws[st.cuda_stream] = torch.empty((need + 7) // 8, dtype=torch.float64,
+                                                                        device=self.device)
                     ws_ptr = ws.data_ptr()
                 _lib.check(self.lib.bh_swd_batch_ordered(
                     B, Lmax, mstride, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),

@@ -303,14 +303,15 @@ class JointTarget(object):
         bt = self._batch or self._build_batch()
         eng = bt['eng']
         B = out.shape[0]
-        noise = eng._as_dev(noise, torch.float64)
-        logL = torch.empty(B, dtype=torch.float64, device=eng.device)
-        misfits = torch.empty((B, self.ntargets + 1), dtype=torch.float64, device=eng.device)
         st = torch.cuda.current_stream(eng.device) if stream is None else stream
         need = eng.lib.bh_likelihood_workspace_bytes(B, self.ntargets, bt['desc']) if self.use_mfma else 0
         ws = bt.setdefault('ws', {}).get(st.cuda_stream)        # one workspace per launch stream
-        if need and (ws is None or ws.numel() * 8 < need):
-            ws = bt['ws'][st.cuda_stream] = torch.empty((need + 7) // 8, dtype=torch.float64, device=eng.device)
+        with torch.cuda.stream(st):                             # allocations belong to the launch stream
+            noise = eng._as_dev(noise, torch.float64)
+            logL = torch.empty(B, dtype=torch.float64, device=eng.device)
+            misfits = torch.empty((B, self.ntargets + 1), dtype=torch.float64, device=eng.device)
+            if need and (ws is None or ws.numel() * 8 < need):
+                ws = bt['ws'][st.cuda_stream] = torch.empty((need + 7) // 8, dtype=torch.float64, device=eng.device)
         with torch.cuda.device(eng.device):
             _lib.check(eng.lib.bh_likelihood_batch(
                 B, self.ntargets, bt['desc'], out.data_ptr(), eng.row, err.data_ptr(), bt['nflags'],

@@ -543,3 +543,57 @@ def test_ragged_batch_is_reordered_transparently(lib, oracle):
     assert np.array_equal(err.cpu().numpy()[sl, 0], werr)
     ok = werr == 0
     assert np.abs(out.cpu().numpy()[sl][ok][:, :11] - want[ok]).max() <= TOL_PHASE
+
+
+def test_more_launches_in_flight_than_queue_slots(lib, oracle):
+    """The work-queue counters live in a ring of slots; a slot is re-used only after the launch that
+    used it has finished (event per slot).  600 small launches on two streams with the ring shrunk to
+    4 slots (BH_SWD_QUEUE_SLOTS, child process): every launch must still produce the oracle's rows
+    (a shared counter would hand models to the wrong launch or skip some)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from bayhunter_amd import _lib
+from bayhunter_amd.engine import ForwardEngine, SwdSpec
+from bayhunter_amd.synthetic import draw_models
+per = np.linspace(1, 41, 7)
+_lib.set_swd_kernel(sys.argv[2])
+eng = ForwardEngine(swd=[SwdSpec('rdispph', per)])
+eng.sort_ragged = False
+sets = [eng.upload(*draw_models(200 + 13 * i, (2, 6), seed=300 + i, sorted_vs=False)) for i in range(6)]
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+outs = []
+for it in range(100):
+    for i, m in enumerate(sets):
+        st = streams[(it + i) %% 2]
+        with torch.cuda.stream(st):
+            outs.append((i, eng.run(m, stream=st)))
+torch.cuda.synchronize()
+ref = [None] * 6
+bad = 0
+for i, (o, e) in outs:
+    o, e = o.cpu().numpy(), e.cpu().numpy()
+    if ref[i] is None:
+        ref[i] = (o, e)
+    bad += int(not (np.array_equal(o, ref[i][0]) and np.array_equal(e, ref[i][1])))
+np.savez(sys.argv[1], bad=bad, **{'o%%d' %% i: ref[i][0] for i in range(6)}, **{'e%%d' %% i: ref[i][1] for i in range(6)})
+""" % ROOT
+    per = np.linspace(1, 41, 7)
+    for kernel, waves in (('lane', '4'), ('team16', '')):
+        path = os.path.join(ROOT, 'gpurun_out', 'slots_test_%s.npz' % kernel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        env = dict(os.environ, BH_SWD_QUEUE_SLOTS='4')
+        if waves:
+            env['BH_SWD_RESIDENT_WAVES'] = waves                      # the queue path of the lane kernel
+        subprocess.run([sys.executable, '-c', code, path, kernel], check=True, env=env, timeout=600)
+        got = np.load(path)
+        assert int(got['bad']) == 0, kernel
+        for i in range(6):
+            H, VP, VS, RHO, nl = draw_models(200 + 13 * i, (2, 6), seed=300 + i, sorted_vs=False)
+            want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, 2, 0)
+            assert np.array_equal(got['e%d' % i][:, 0], werr), (kernel, i)
+            ok = werr == 0
+            assert np.abs(got['o%d' % i][ok] - want[ok]).max() <= TOL_PHASE, (kernel, i)

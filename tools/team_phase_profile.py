@@ -1,0 +1,62 @@
+"""GPU-box diagnostic: where does a round of the 64-lane team kernel spend its cycles?
+
+Builds a -DBH_TEAM_PROFILE copy of the library into gpurun_out/ (never the shipped one), runs
+BASELINE-shaped batches through the 64-lane team kernel and prints shader-clock cycles per phase
+(driver | plan | assemble | chain | consume), rounds per search and the wall time per call.
+
+    python tools/team_phase_profile.py > gpurun_out/team_phase_profile.txt
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayhunter_amd import _lib  # noqa: E402
+
+
+def main():
+    so = os.path.join(ROOT, 'gpurun_out', 'libbayhunter_amd_prof.so')
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.run(['/opt/rocm/bin/hipcc'] + _lib.HIPCC_FLAGS + ['-DBH_TEAM_PROFILE'] + _lib.SOURCES + ['-o', so],
+                   cwd=_lib.CSRC, check=True)
+    _lib.LIB_PATH = so
+    import torch
+    from bayhunter_amd.engine import ForwardEngine, SwdSpec
+    from bayhunter_amd.synthetic import draw_models
+    lib = _lib.load()
+    lib.bh_debug_team_profile.argtypes = [C.c_void_p, C.c_int]
+    names = ['driver', 'plan', 'assemble', 'chain', 'consume']
+    print('# %s' % torch.cuda.get_device_name(0))
+    for L, P, B, mode in ((5, 20, 1024, 'team'), (10, 21, 1024, 'team'), (15, 21, 64, 'team'), (15, 21, 1024, 'team')):
+        H, VP, VS, RHO, nl = draw_models(B, L, seed=100 + L)
+        eng = ForwardEngine(swd=[SwdSpec('rdispph', np.linspace(1, 41, P))])
+        dm = eng.upload(H, VP, VS, RHO, nl)
+        _lib.set_swd_kernel(mode)
+        eng.run(dm)
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 8)()
+        lib.bh_debug_team_profile(buf, 1)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.run(dm)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        lib.bh_debug_team_profile(buf, 1)
+        v = np.array(list(buf), dtype=np.float64)
+        nsearch, rounds = v[7], v[6]
+        print('L=%d P=%d B=%d: %.3f ms per call, %.1f rounds per search (%.1f per period)'
+              % (L, P, B, ms, rounds / nsearch, rounds / nsearch / P))
+        tot = v[:5].sum()
+        for i, n in enumerate(names):
+            print('   %-9s %8.0f cycles per round  (%4.1f %%)' % (n, v[i] / rounds, 100 * v[i] / tot))
+        print('   total     %8.0f cycles per round, %.0f cycles per search' % (tot / rounds, tot / nsearch))
+    _lib.set_swd_kernel('auto')
+
+
+if __name__ == '__main__':
+    main()
