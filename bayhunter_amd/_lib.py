@@ -173,8 +173,10 @@ def check(rc):
 
 
 def set_swd_kernel(mode):
-    """'auto' | 'lane' | 'team' | 'team32' | 'team16' | 'team8' (include/bayhunter_amd.h, bh_swd_set_kernel)."""
-    check(load().bh_swd_set_kernel({'auto': 0, 'lane': 1, 'team': 2, 'team32': 3, 'team16': 4, 'team8': 5}[mode]))
+    """'auto' | 'lane' | 'team' | 'team32' | 'team16' | 'team8' | 'team128' | 'team256'
+    (include/bayhunter_amd.h, bh_swd_set_kernel)."""
+    check(load().bh_swd_set_kernel({'auto': 0, 'lane': 1, 'team': 2, 'team32': 3, 'team16': 4, 'team8': 5,
+                                    'team128': 6, 'team256': 7}[mode]))
 
 
 def device_count():

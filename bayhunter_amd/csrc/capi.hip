@@ -211,7 +211,7 @@ int bh_set_device(int device)
 
 int bh_swd_set_kernel(int mode)
 {
-    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM8) return fail_arg("unknown kernel mode");
+    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM256) return fail_arg("unknown kernel mode");
     g_swd_mode.store(mode, std::memory_order_relaxed);
     return BH_OK;
 }
@@ -307,12 +307,16 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
         }
     }
     if (swd_mode == BH_SWD_LANE) team = false;
-    if (swd_mode >= BH_SWD_TEAM) {
+    if (swd_mode == BH_SWD_TEAM128 || swd_mode == BH_SWD_TEAM256) {
+        team = true;
+        width = swd_mode == BH_SWD_TEAM128 ? 128 : 256;
+    } else if (swd_mode >= BH_SWD_TEAM) {
         team = true;
         const int i = swd_mode == BH_SWD_TEAM8 ? 3 : swd_mode == BH_SWD_TEAM16 ? 2 : swd_mode == BH_SWD_TEAM32 ? 1 : 0;
         width = widths[i];
         team_resident = waves_of[i] > 0 ? (int)waves_of[i] : 1;
     }
+    if (team && bh::swd_team_lds_bytes(Lmax, width) > 160 * 1024) { team = true; width = 64; }   // 100 layers x 256 lanes
     hipError_t le = team ? bh::launch_swd_team(A, width, team_resident, (hipStream_t)stream)
                          : bh::launch_swd(A, resident, (hipStream_t)stream);
     rc = release_queue_slot(slot, (hipStream_t)stream);    // also after a failed launch: the slot is free

@@ -96,6 +96,7 @@ struct QueueSrc {
         return nl;
     }
     __device__ __forceinline__ void done(int err) { A.err[cur * A.ntargets + t] = err; }
+    __device__ __forceinline__ void sphere(LdsLay &lay, int mmax, int ifunc) { swd_sphere(lay, mmax, ifunc); }
 };
 
 // 2 waves per SIMD: the search state + one Dunkin layer need ~250 VGPRs; pin the allocator there
@@ -168,6 +169,13 @@ struct TeamSrc {
     {
         if (lane == 0) A.err[b * A.ntargets + t] = err;
     }
+    // The team shares one copy of the model: the lanes of a wave transform it in lock step (every
+    // lane reads a value before any lane writes it), a second wave must not transform it again.
+    __device__ __forceinline__ void sphere(TeamLay &lay, int mmax, int ifunc)
+    {
+        if (threadIdx.x < SWD_T) swd_sphere(lay, mmax, ifunc);
+        __syncthreads();
+    }
 };
 
 // TEAM lanes per search, 64/TEAM searches per wave (workgroup = one wave).  TEAM = 64 is the lowest
@@ -180,18 +188,20 @@ struct TeamSrc {
 // Diagnostic build only (-DBH_TEAM_PROFILE, tools/team_phase_profile.py): shader-clock cycles per
 // phase of the 64-lane team loop, summed over all searches; read back with bh_debug_team_profile.
 #if defined(BH_TEAM_PROFILE)
-__device__ unsigned long long g_team_prof[8];
-#define BH_TP_DECL unsigned long long tp_[6] = {0, 0, 0, 0, 0, 0}, tp_t0_ = clock64(), tp_t1_
+__device__ unsigned long long g_team_prof[16];
+#define BH_TP_DECL unsigned long long tp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_t0_ = clock64(), tp_t1_
 #define BH_TP(i) (tp_t1_ = clock64(), tp_[i] += tp_t1_ - tp_t0_, tp_t0_ = tp_t1_)
+#define BH_TP_COUNT(i, n) (tp_[i] += (n))
 #define BH_TP_FLUSH(rounds)                                                                  \
     if (threadIdx.x == 0) {                                                                  \
-        for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_team_prof[i_], tp_[i_]);                 \
-        atomicAdd(&g_team_prof[6], (unsigned long long)(rounds));                            \
-        atomicAdd(&g_team_prof[7], 1ull);                                                    \
+        for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_team_prof[i_], tp_[i_]);                \
+        atomicAdd(&g_team_prof[14], (unsigned long long)(rounds));                           \
+        atomicAdd(&g_team_prof[15], 1ull);                                                   \
     }
 #else
 #define BH_TP_DECL
 #define BH_TP(i)
+#define BH_TP_COUNT(i, n)
 #define BH_TP_FLUSH(rounds)
 #endif
 
@@ -200,7 +210,8 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
 {
     extern __shared__ double tlds[];
     constexpr int NSUB = SWD_T / TEAM;
-    const int sub = NSUB == 1 ? 0 : threadIdx.x / TEAM, lane = NSUB == 1 ? threadIdx.x : threadIdx.x % TEAM;
+    static_assert(NSUB > 1, "64 lanes and more per search: swd_teamw_body");
+    const int sub = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
     const int t = blockIdx.y;
     const SwdTargetDev tg = A.tg[t];
     const int nm = A.Lmax > TEAM ? A.Lmax : TEAM;
@@ -208,35 +219,13 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
     const int per_team = nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * A.Lmax + 1) / 2;
     double *mats = tlds + (long)sub * per_team, *trials = mats + (long)nm * SWD_NCA, *dels = trials + SWD_TEAM_NT;
     TeamLay lay{(float *)(dels + SWD_TEAM_NT), A.Lmax};
-    TeamSrc src{A, tg, t, lane, TEAM, 0, (long)blockIdx.x, NSUB == 1 ? nullptr : A.counters + t};
+    TeamSrc src{A, tg, t, lane, TEAM, 0, (long)blockIdx.x, A.counters + t};
     const double *per = A.periods + tg.per_off;
     SwdState S;
     swd_state_init(S);
-    if constexpr (NSUB == 1) {
-        BH_TP_DECL;
-        long rounds = 0;
-        for (;;) {
-            swd_driver(S, lay, src, tg, per, A.B);
-            if (S.st == SWD_ST_DONE) break;
-            BH_TP(0);
-            const int nt = swd_team_plan(S, TEAM, trials);
-            __syncthreads();
-            BH_TP(1);
-            swd_team_assemble(lay, lane, TEAM, tg.iwave, S, nt, trials, mats);
-            __syncthreads();
-            BH_TP(2);
-            if (tg.iwave == 2 && nt <= 8) swd_team_chain_ray5(lay, lane, S, nt, trials, mats, dels);
-            else swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
-            __syncthreads();
-            BH_TP(3);
-            swd_team_consume(S, nt, trials, dels);
-            __syncthreads();
-            BH_TP(4);
-            rounds++;
-        }
-        BH_TP_FLUSH(rounds);
-        (void)rounds;
-    } else {
+    NevRegs nv;
+    swd_nev_init(nv);
+    {
         // A team whose search is over keeps walking through the phases with nt = 0 (no trial, no
         // matrix, no value consumed): cheaper than predicating every phase on a per-team flag.
         bool live = true;
@@ -253,16 +242,15 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
             if (tg.iwave == 2 && 8 * nt <= TEAM) swd_team_chain_ray5(lay, lane, S, nt, trials, mats, dels);
             else swd_team_chain(lay, lane, tg.iwave, S, nt, trials, mats, dels);
             __syncthreads();
-            swd_team_consume(S, nt, trials, dels);
+            swd_team_consume(S, nv, nt, trials, dels);
             __syncthreads();
         }
     }
 }
 
-// The 64-lane form fits 256 VGPRs as it is (2 waves per SIMD).  The narrower forms carry per-team
-// liveness through the divergent driver call and want ~310 registers: pinned to 2 waves per SIMD
-// they spill ~50 dwords and are still 1.3-1.4x faster than at one wave per SIMD (measured).
-__global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A) { swd_team_body<64>(A); }
+// The narrower forms carry per-team liveness through the divergent driver call and want ~310
+// registers: pinned to 2 waves per SIMD they spill ~50 dwords and are still 1.3-1.4x faster than at
+// one wave per SIMD (measured).
 __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team32_kernel(SwdArgs A)
 {
     swd_team_body<32>(A);
@@ -275,6 +263,221 @@ __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 {
     swd_team_body<8>(A);
 }
+
+// ---------------------------------------------------------------------------------- SWD, wide teams
+// 64*W lanes (W waves, one workgroup) per search: swd_team.h, "Wide teams".  Per round
+//   plan      every lane runs swd_teamw_plan in registers and keeps the trials it needs: the one it
+//             assembles a layer matrix for, the one its quad chains, and trial (lane & 63) for matching
+//   assemble  lane (j, r): matrix of layer r at trial j -> LDS, column-major           | barrier
+//   chain     Rayleigh: quad q of wave w propagates trial 16 w + q (component i on lane i, the fifth
+//             on all four; max-reduce and re-gather by DPP quad permutes); Love: lane j   | barrier
+//   consume   every lane: values matched by (omega, c) through ballots, swd_control / swd_driver
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double x)
+{
+    // (all four lanes of every quad are active wherever this is used)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double x, int j)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
+    return __hiloint2double(hi, lo);
+}
+
+// The search state of a wide team is the same in every lane.  Telling the compiler so (a value read
+// from the first lane is uniform by construction) turns the branches of the control code into scalar
+// branches: no exec-mask bookkeeping, no saved masks to spill.
+__device__ __forceinline__ double uni(double x)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+template <class T>
+__device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+struct TeamwVals {
+    double mc, mom, dl;                   // slot (lane & 63) of the round and its value
+    int nt, scan0, stride, nscan;
+#if defined(BH_TEAM_PROFILE)
+    unsigned long long *tp, *t0;
+    __device__ __forceinline__ void probe(int i) const { const unsigned long long t = clock64(); tp[i] += t - *t0; *t0 = t; }
+    __device__ __forceinline__ void count(int i, int n) const { tp[i] += n; }
+#else
+    __device__ __forceinline__ void probe(int) const {}
+    __device__ __forceinline__ void count(int, int) const {}
+#endif
+    __device__ __forceinline__ int find(double om, double c) const
+    {
+        const unsigned long long m = __ballot(mc == c && mom == om && (int)(threadIdx.x & 63) < nt);
+        return m ? __ffsll((long long)m) - 1 : -1;
+    }
+    __device__ __forceinline__ double del(int j) const { return readlane_d(dl, j); }
+    __device__ __forceinline__ double c(int j) const { return readlane_d(mc, j); }
+    // scan trials i, i+1, ... in a row that are valid and whose value has sign bit `neg`
+    __device__ __forceinline__ int run(int i, bool neg) const
+    {
+        const bool same = (mc == mc) && ((__double2hiint(dl) < 0) == neg) && (int)(threadIdx.x & 63) < nt;
+        unsigned long long m = __ballot(same) >> (scan0 + i * stride);
+        int n;
+        if (stride == 2) {
+            const unsigned long long stop = ~m & 0x5555555555555555ull;     // scan slots are the even ones
+            n = stop ? (__ffsll((long long)stop) - 1) >> 1 : 32;
+        } else {
+            const unsigned long long stop = ~m;
+            n = stop ? __ffsll((long long)stop) - 1 : 64;
+        }
+        return n < nscan - i ? n : nscan - i;
+    }
+};
+
+// Rayleigh chain of trial (qc, qom) on the calling lane's quad; matrices of its layers at m0.
+// Operation for operation swd_dunkin_apply (ee = e * ca in the reference's order, normc; the
+// max-abs of normc skips NaN entries exactly like v_max_f64 does).
+struct QuadCols {                 // column i (this lane's component) and column 4 of one layer matrix
+    double a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+};
+__device__ __forceinline__ void quad_load(QuadCols &q, const double *p, int i)
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t a01 = *(const d2_t *)(p + 6 * i), a23 = *(const d2_t *)(p + 6 * i + 2);
+    const d2_t b01 = *(const d2_t *)(p + 24), b23 = *(const d2_t *)(p + 26);
+    q.a0 = a01.x; q.a1 = a01.y; q.a2 = a23.x; q.a3 = a23.y; q.a4 = p[6 * i + 4];
+    q.b0 = b01.x; q.b1 = b01.y; q.b2 = b23.x; q.b3 = b23.y; q.b4 = p[28];
+}
+__device__ __forceinline__ void quad_apply(double e[5], const QuadCols &q)
+{
+    const double eeA = ((((0.0 + e[0] * q.a0) + e[1] * q.a1) + e[2] * q.a2) + e[3] * q.a3) + e[4] * q.a4;
+    const double eeB = ((((0.0 + e[0] * q.b0) + e[1] * q.b1) + e[2] * q.b2) + e[3] * q.b3) + e[4] * q.b4;
+    double t1 = fabs(eeA);
+    t1 = __builtin_fmax(t1, dpp_quad<0xB1>(t1));      // lanes 0<->1, 2<->3
+    t1 = __builtin_fmax(t1, dpp_quad<0x4E>(t1));      // lanes 0<->2, 1<->3
+    t1 = __builtin_fmax(t1, fabs(eeB));
+    if (t1 < 1.e-40) t1 = 1.0;
+    const Recip by_t1 = recip_of(t1);
+    const double enA = qdiv(eeA, by_t1);
+    e[4] = qdiv(eeB, by_t1);
+    e[0] = dpp_quad<0x00>(enA);
+    e[1] = dpp_quad<0x55>(enA);
+    e[2] = dpp_quad<0xAA>(enA);
+    e[3] = dpp_quad<0xFF>(enA);
+}
+template <class Lay>
+__device__ __forceinline__ double swd_teamw_chain_quad(const Lay &lay, const SwdState &S, double qc, double qom,
+                                                       const double *m0)
+{
+    const int i = threadIdx.x & 3;
+    const int nlm = S.mmax - S.llw;
+    const double wvno = qom / qc;
+    double omega = qom;
+    if (omega < 1.0e-4) omega = 1.0e-4;
+    double e[5];
+    swd_ray_halfspace(lay, S.mmax, wvno, wvno * wvno, omega, e);
+    // two layers per trip, their columns loaded one layer ahead into alternating register sets
+    const double *p = m0 + (long)(nlm - 1) * SWD_MAT;
+    QuadCols qa, qb;
+    int r = nlm;
+    if (r > 0) quad_load(qa, p, i);
+    while (r >= 2) {
+        quad_load(qb, p - SWD_MAT, i);
+        quad_apply(e, qa);
+        if (r > 2) quad_load(qa, p - 2 * SWD_MAT, i);
+        quad_apply(e, qb);
+        p -= 2 * SWD_MAT;
+        r -= 2;
+    }
+    if (r == 1) quad_apply(e, qa);
+    return (S.llw != 1) ? swd_ray_water(lay, wvno, omega, e) : e[0];
+}
+
+template <int W>
+__device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
+{
+    extern __shared__ double tlds[];
+    constexpr int NL = SWD_T * W;
+    const int lane = threadIdx.x, wl = lane & 63, wave = uni(lane >> 6);
+    const int t = blockIdx.y;
+    const SwdTargetDev tg = A.tg[t];
+    const int nm = A.Lmax > NL ? A.Lmax : NL;
+    double *mats = tlds, *dels = mats + (long)nm * SWD_MAT, *perl = dels + SWD_TEAMW_NT, *nevt = perl + BH_NP;
+    double *tcl = nevt + 24 * W, *toml = tcl + SWD_TEAMW_NT;
+    TeamLay lay{(float *)(toml + SWD_TEAMW_NT), A.Lmax};
+    // every wave runs the control code for itself: a Neville table per wave (the waves are not in
+    // step inside a phase)
+    NevMem nv{nevt + 24 * wave, nevt + 24 * wave + 12};
+    for (int k = lane; k < tg.nper; k += NL) perl[k] = A.periods[tg.per_off + k];   // (TeamSrc::next syncs)
+    TeamSrc src{A, tg, t, lane, NL, 0, (long)blockIdx.x, nullptr};
+    SwdState S;
+    swd_state_init(S);
+    BH_TP_DECL;
+    long rounds = 0;
+    for (;;) {
+        swd_driver(S, lay, src, tg, perl, A.B, true);
+        if (S.st == SWD_ST_DONE) break;
+        BH_TP(0);
+        const int nlm = S.mmax - S.llw;
+        int cap = nlm > 0 ? NL / nlm : SWD_TEAMW_NT;
+        if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;                // one quad per Rayleigh trial
+        if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
+        if (cap < 1) cap = 1;
+        const TeamwRound R = swd_teamw_round(S, tg, perl, cap);
+        const int nt = R.nt;
+        double mc, mom;                                                 // slot wl of the plan
+        swd_teamw_trial(R, S, wl < nt ? wl : 0, &mc, &mom);
+        if (lane < nt) { tcl[lane] = mc; toml[lane] = mom; }
+        __syncthreads();
+        BH_TP(1);
+        const int ja = (cap > 1 && nlm > 0) ? lane / nlm : 0, ra = lane - ja * nlm;
+        const int jq = 16 * wave + (wl >> 2);
+        if (cap > 1) {
+            if (ja < nt && nlm > 0) {
+                const double ac = tcl[ja];
+                if (ac == ac)                                           // (NaN: a scan slot out of bounds)
+                    swd_teamw_assemble_one(lay, tg.iwave, S, ra, ac, toml[ja], mats + (long)lane * SWD_MAT);
+            }
+        } else {
+            for (int r = lane; r < nlm; r += NL)
+                swd_teamw_assemble_one(lay, tg.iwave, S, r, S.ceval, S.omega, mats + (long)r * SWD_MAT);
+        }
+        const bool qvalid = jq < nt;
+        const double qc = qvalid ? tcl[jq] : S.ceval, qom = qvalid ? toml[jq] : S.omega;
+        __syncthreads();
+        BH_TP(2);
+        if (tg.iwave == 2) {
+            const double del = swd_teamw_chain_quad(lay, S, qc, qom, mats + (long)(qvalid ? jq : 0) * nlm * SWD_MAT);
+            if (qvalid && (wl & 3) == 0) dels[jq] = del;
+        } else if (lane < nt) {
+            dels[lane] = swd_teamw_chain_one(lay, 1, S, mc, mom, mats + (long)lane * nlm * SWD_MAT);
+        }
+        __syncthreads();
+        BH_TP(3);
+#if defined(BH_TEAM_PROFILE)
+        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, R.scan0, R.stride, R.nscan, tp_, &tp_t0_};
+#else
+        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, R.scan0, R.stride, R.nscan};
+#endif
+        const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
+        BH_TP(4);
+        BH_TP_COUNT(8, used);
+        BH_TP_COUNT(9, nt);
+        (void)used;
+        rounds++;
+    }
+    BH_TP_FLUSH(rounds);
+    (void)rounds;
+}
+
+__global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A) { swd_teamw_body<1>(A); }
+__global__ __launch_bounds__(2 * SWD_T) void swd_team128_kernel(SwdArgs A) { swd_teamw_body<2>(A); }
+__global__ __launch_bounds__(4 * SWD_T) void swd_team256_kernel(SwdArgs A) { swd_teamw_body<4>(A); }
 
 // -------------------------------------------------------------------------------------------- RF
 // bit reversal (+ 1/sqrt(n)) and radix-2 butterflies of Mb buffers in LDS; all threads of the group
@@ -399,7 +602,7 @@ extern "C" int bh_debug_team_profile(unsigned long long *out, int reset)
 {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_team_prof), sizeof(g_team_prof)) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_team_prof), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
@@ -407,33 +610,45 @@ extern "C" int bh_debug_team_profile(unsigned long long *out, int reset)
 #endif
 
 // ---------------------------------------------------------------------------------------- launch
-// LDS of one wave of the team kernel with `team` lanes per search
+// LDS of one workgroup of the team kernels with `team` lanes per search
 size_t swd_team_lds_bytes(int Lmax, int team)
 {
+    if (team >= SWD_T) {           // wide teams: mats[max(Lmax, lanes)][SWD_MAT], dels, periods, layer stack
+        const int nm = Lmax > team ? Lmax : team;
+        return ((size_t)nm * SWD_MAT + 3 * SWD_TEAMW_NT + BH_NP + 24 * (team / SWD_T) + (4 * Lmax + 1) / 2) * sizeof(double);
+    }
     const int nsub = SWD_T / team;
     const int nm = Lmax > team ? Lmax : team;
     return (size_t)nsub * (nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * Lmax + 1) / 2) * sizeof(double);
 }
 
+static int team_index(int team)
+{
+    return team == 8 ? 0 : team == 16 ? 1 : team == 32 ? 2 : team == 128 ? 4 : team == 256 ? 5 : 3;
+}
+
 hipError_t launch_swd_team(const SwdArgs &A, int team, int resident_waves, hipStream_t stream)
 {
-    if (team != 8 && team != 16 && team != 32) team = 64;
-    const int nsub = SWD_T / team;
+    if (team != 8 && team != 16 && team != 32 && team != 128 && team != 256) team = 64;
     size_t lds = swd_team_lds_bytes(A.Lmax, team);
-    static size_t lds_set[4][16] = {{0}, {0}, {0}, {0}};
+    static size_t lds_set[6][16] = {{0}, {0}, {0}, {0}, {0}, {0}};
     void (*kern)(SwdArgs) = team == 8 ? swd_team8_kernel : team == 16 ? swd_team16_kernel
-                          : team == 32 ? swd_team32_kernel : swd_team_kernel;
-    hipError_t e = ensure_dyn_lds((const void *)kern, lds, lds_set[team == 8 ? 3 : team == 16 ? 2 : team == 32 ? 1 : 0]);
+                          : team == 32 ? swd_team32_kernel : team == 128 ? swd_team128_kernel
+                          : team == 256 ? swd_team256_kernel : swd_team_kernel;
+    hipError_t e = ensure_dyn_lds((const void *)kern, lds, lds_set[team_index(team)]);
     if (e != hipSuccess) return e;
-    int gx = (A.B + nsub - 1) / nsub;
-    if (nsub > 1) {
-        // persistent waves: no more than stay resident; their teams drain the queue
-        int per_target = resident_waves / A.ntargets;
-        if (per_target < 1) per_target = 1;
-        if (gx > per_target) gx = per_target;
-        e = hipMemsetAsync(A.counters, 0, BH_NT * sizeof(unsigned int), stream);
-        if (e != hipSuccess) return e;
+    if (team >= SWD_T) {           // one workgroup per search; the hardware back-fills them
+        hipLaunchKernelGGL(kern, dim3(A.B, A.ntargets), dim3(team), lds, stream, A);
+        return hipGetLastError();
     }
+    const int nsub = SWD_T / team;
+    int gx = (A.B + nsub - 1) / nsub;
+    // persistent waves: no more than stay resident; their teams drain the queue
+    int per_target = resident_waves / A.ntargets;
+    if (per_target < 1) per_target = 1;
+    if (gx > per_target) gx = per_target;
+    e = hipMemsetAsync(A.counters, 0, BH_NT * sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(gx, A.ntargets), dim3(SWD_T), lds, stream, A);
     return hipGetLastError();
 }

@@ -390,9 +390,95 @@ struct SwdState {
     // getsol / nevill
     int st, ev, idir, nev, nctrl, m, nbrk;
     double c1, c2, c3, del1, del2, del3, clow, del1st, ceval;
+};
+
+// The (x, y) table of nevill's inverse interpolation (surfdisp96.f:572,642-658; up to 11 points),
+// kept apart from the state because where it should live depends on the kernel:
+//   NevRegs  in registers (throughput kernel: one search per lane; indexed through if-chains)
+//   NevMem   in memory (LDS of a team / host arrays): 12 doubles each, entries 1..11 used.  A team runs
+//            the control code redundantly on all lanes, so 44 fewer live registers and no if-chains
+//            shorten every step of it.
+struct NevRegs {
     double x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11;
     double y1, y2, y3, y4, y5, y6, y7, y8, y9, y10, y11;
 };
+struct NevMem {
+    double *x, *y;
+};
+BH_DEV void swd_nev_init(NevRegs &n)
+{
+    n.x1 = n.x2 = n.x3 = n.x4 = n.x5 = n.x6 = n.x7 = n.x8 = n.x9 = n.x10 = n.x11 = 0;
+    n.y1 = n.y2 = n.y3 = n.y4 = n.y5 = n.y6 = n.y7 = n.y8 = n.y9 = n.y10 = n.y11 = 0;
+}
+BH_DEV void swd_nev_init(NevMem &n)
+{
+    for (int i = 0; i < 12; i++) { n.x[i] = 0; n.y[i] = 0; }
+}
+
+// One pass of Neville inverse interpolation (surfdisp96.f:642-658).  nev2: append (c3, del3) as point
+// m+1, else restart the table from the bracket ends.  Returns false when the guard
+// abs(denom) < 1e-10 abs(y(m+1)) fires (-> bisection); else *x1 receives the new estimate x(1).
+BH_DEV bool swd_neville(NevRegs &n, int &m, bool nev2, double c1, double del1, double c2, double del2,
+                        double c3, double del3, double *x1)
+{
+    double ym1;                       // y(m+1)
+    if (nev2) {                       // x(m+1)=c3, y(m+1)=del3
+        ym1 = del3;
+        if (m == 1) { n.x2 = c3; n.y2 = del3; } else if (m == 2) { n.x3 = c3; n.y3 = del3; }
+        else if (m == 3) { n.x4 = c3; n.y4 = del3; } else if (m == 4) { n.x5 = c3; n.y5 = del3; }
+        else if (m == 5) { n.x6 = c3; n.y6 = del3; } else if (m == 6) { n.x7 = c3; n.y7 = del3; }
+        else if (m == 7) { n.x8 = c3; n.y8 = del3; } else if (m == 8) { n.x9 = c3; n.y9 = del3; }
+        else if (m == 9) { n.x10 = c3; n.y10 = del3; } else { n.x11 = c3; n.y11 = del3; }
+    } else {
+        n.x1 = c1; n.y1 = del1; n.x2 = c2; n.y2 = del2; m = 1;
+        ym1 = del2;
+    }
+    // j = m .. 1 (surfdisp96.f:649-654)
+    bool bad = false;
+    const double guard = 1.0e-10 * fabs(ym1);
+#define BH_NEV_STEP(J, XJ, YJ, XJ1)                                               \
+    if (!bad && m >= J) {                                                         \
+        double denom = ym1 - n.YJ;                                                \
+        if (fabs(denom) < guard) bad = true;                                      \
+        else n.XJ = (-n.YJ * n.XJ1 + ym1 * n.XJ) / denom;                         \
+    }
+    BH_NEV_STEP(10, x10, y10, x11)
+    BH_NEV_STEP(9, x9, y9, x10)
+    BH_NEV_STEP(8, x8, y8, x9)
+    BH_NEV_STEP(7, x7, y7, x8)
+    BH_NEV_STEP(6, x6, y6, x7)
+    BH_NEV_STEP(5, x5, y5, x6)
+    BH_NEV_STEP(4, x4, y4, x5)
+    BH_NEV_STEP(3, x3, y3, x4)
+    BH_NEV_STEP(2, x2, y2, x3)
+    BH_NEV_STEP(1, x1, y1, x2)
+#undef BH_NEV_STEP
+    *x1 = n.x1;
+    return !bad;
+}
+BH_DEV bool swd_neville(NevMem &n, int &m, bool nev2, double c1, double del1, double c2, double del2,
+                        double c3, double del3, double *x1)
+{
+    double ym1;
+    if (nev2) {
+        n.x[m + 1] = c3; n.y[m + 1] = del3;
+        ym1 = del3;
+    } else {
+        n.x[1] = c1; n.y[1] = del1; n.x[2] = c2; n.y[2] = del2; m = 1;
+        ym1 = del2;
+    }
+    const double guard = 1.0e-10 * fabs(ym1);
+    double xj1 = n.x[m + 1];          // x(j+1) of the running pass
+    for (int j = m; j >= 1; j--) {
+        const double yj = n.y[j];
+        const double denom = ym1 - yj;
+        if (fabs(denom) < guard) return false;
+        xj1 = (-yj * xj1 + ym1 * n.x[j]) / denom;
+        n.x[j] = xj1;
+    }
+    *x1 = xj1;
+    return true;
+}
 
 BH_DEV void swd_state_init(SwdState &S)
 {
@@ -402,8 +488,6 @@ BH_DEV void swd_state_init(SwdState &S)
     S.omega = 0; S.cprev = 0; S.ck = 0;
     S.st = SWD_ST_DONE; S.ev = SWD_EV_FETCH; S.idir = 1; S.nev = 1; S.nctrl = 1; S.m = 1; S.nbrk = 0;
     S.c1 = S.c2 = S.c3 = S.del1 = S.del2 = S.del3 = S.clow = S.del1st = S.ceval = 0;
-    S.x1 = S.x2 = S.x3 = S.x4 = S.x5 = S.x6 = S.x7 = S.x8 = S.x9 = S.x10 = S.x11 = 0;
-    S.y1 = S.y2 = S.y3 = S.y4 = S.y5 = S.y6 = S.y7 = S.y8 = S.y9 = S.y10 = S.y11 = 0;
 }
 
 // next trial velocity of the bracketing scan (label 1000, surfdisp96.f:448-460); may turn the scan
@@ -425,11 +509,14 @@ BH_DEV double swd_bracket_next(double &c1, int &idir, double clow, double dc)
 //   src      task source.  `int next(Lay &lay, double *&out, double *&cws, double *&cbws)` loads
 //            the next model of this lane's target into `lay` and returns its layer count (>= 1), or
 //            0 when the queue is drained; `void done(int err)` reports the reference's err flag of
-//            the task just finished.
+//            the task just finished; `void sphere(Lay &, int mmax, int ifunc)` applies swd_sphere to
+//            the model just loaded, exactly once (a team shares one copy of the model).
 //   cws/cbws per-task c(k)/cb(k) arrays for mode > 1 (stride `wss` doubles), unused for mode 1
+//   allow_fetch  false: return (with S.ev == SWD_EV_FETCH pending) instead of loading the next task --
+//            used where the driver runs in the middle of a round (swd_team.h, wide teams)
 template <class Lay, class Src>
 BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
-                       const double *BH_RESTRICT per, int wss)
+                       const double *BH_RESTRICT per, int wss, bool allow_fetch = true)
 {
     const double TWOPI = 2.0 * 3.141592653589793;
     const double one = 1.0e-2;
@@ -440,12 +527,13 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
     const bool multimode = nmode > 1;
     while (S.ev != SWD_EV_NONE) {
         if (S.ev == SWD_EV_FETCH) {                   // surfdisp96.f:96-222 for the next model
+            if (!allow_fetch) { S.st = SWD_ST_DONE; break; }
             S.mmax = src.next(lay, S.out, S.cws, S.cbws);
             if (S.mmax <= 0) { S.st = SWD_ST_DONE; S.ev = SWD_EV_NONE; break; }
             S.err = 0;
             S.llw = 1;
             if (lay.b(0) <= 0.0f) S.llw = 2;
-            if (tg.iflsph == 1) swd_sphere(lay, S.mmax, ifunc);
+            if (tg.iflsph == 1) src.sphere(lay, S.mmax, ifunc);   // once per model (shared by a team)
             int jmn = 0, jsol = 1;                    // extremal velocities, surfdisp96.f:139-156
             S.betmx = -1.e20f;
             float betmn = 1.e20f;
@@ -541,7 +629,8 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
 }
 
 // ---- control: getsol + nevill as a resumable machine, fed the period-equation value at S.ceval -----
-BH_DEV void swd_control(SwdState &S, double del)
+template <class Nev>
+BH_DEV void swd_control(SwdState &S, double del, Nev &nv)
 {
     const double dc = (double)0.005f;
     const double pct = (double)0.01f;               // `0.01` literal in nevill is real*4
@@ -588,42 +677,9 @@ BH_DEV void swd_control(SwdState &S, double del)
                 double ss1 = fabs(S.del1), s1 = pct * ss1, ss2 = fabs(S.del2), s2 = pct * ss2;
                 bool do_half = (s1 > ss2 || s2 > ss1 || S.nev == 0);
                 if (!do_half) {
-                    double ym1;                       // y(m+1)
-                    const int m = S.m;
-                    const double c3 = S.c3, del3 = S.del3;
-                    if (S.nev == 2) {                 // x(m+1)=c3, y(m+1)=del3
-                        ym1 = del3;
-                        if (m == 1) { S.x2 = c3; S.y2 = del3; } else if (m == 2) { S.x3 = c3; S.y3 = del3; }
-                        else if (m == 3) { S.x4 = c3; S.y4 = del3; } else if (m == 4) { S.x5 = c3; S.y5 = del3; }
-                        else if (m == 5) { S.x6 = c3; S.y6 = del3; } else if (m == 6) { S.x7 = c3; S.y7 = del3; }
-                        else if (m == 7) { S.x8 = c3; S.y8 = del3; } else if (m == 8) { S.x9 = c3; S.y9 = del3; }
-                        else if (m == 9) { S.x10 = c3; S.y10 = del3; } else { S.x11 = c3; S.y11 = del3; }
-                    } else {
-                        S.x1 = S.c1; S.y1 = S.del1; S.x2 = S.c2; S.y2 = S.del2; S.m = 1;
-                        ym1 = S.del2;
-                    }
-                    // Neville inverse interpolation, j = m .. 1 (surfdisp96.f:649-654)
-                    bool bad = false;
-                    const double guard = 1.0e-10 * fabs(ym1);
-#define BH_NEV_STEP(J, XJ, YJ, XJ1)                                               \
-    if (!bad && S.m >= J) {                                                       \
-        double denom = ym1 - S.YJ;                                                \
-        if (fabs(denom) < guard) bad = true;                                      \
-        else S.XJ = (-S.YJ * S.XJ1 + ym1 * S.XJ) / denom;                         \
-    }
-                    BH_NEV_STEP(10, x10, y10, x11)
-                    BH_NEV_STEP(9, x9, y9, x10)
-                    BH_NEV_STEP(8, x8, y8, x9)
-                    BH_NEV_STEP(7, x7, y7, x8)
-                    BH_NEV_STEP(6, x6, y6, x7)
-                    BH_NEV_STEP(5, x5, y5, x6)
-                    BH_NEV_STEP(4, x4, y4, x5)
-                    BH_NEV_STEP(3, x3, y3, x4)
-                    BH_NEV_STEP(2, x2, y2, x3)
-                    BH_NEV_STEP(1, x1, y1, x2)
-#undef BH_NEV_STEP
-                    if (!bad) {
-                        S.c3 = S.x1;
+                    double x1;
+                    if (swd_neville(nv, S.m, S.nev == 2, S.c1, S.del1, S.c2, S.del2, S.c3, S.del3, &x1)) {
+                        S.c3 = x1;
                         S.nev = 2;
                         S.m = S.m + 1;
                         if (S.m > 10) S.m = 10;
@@ -660,6 +716,8 @@ BH_DEV void swd_lane(Lay &lay, Src &src, const SwdTargetDev &tg, const double *B
 {
     SwdState S;
     swd_state_init(S);
+    NevRegs nv;
+    swd_nev_init(nv);
     long nc = 0;
     for (;;) {
         swd_driver(S, lay, src, tg, per, wss);
@@ -668,7 +726,7 @@ BH_DEV void swd_lane(Lay &lay, Src &src, const SwdTargetDev &tg, const double *B
         double del = (tg.iwave == 1) ? swd_dltar1(lay, S.mmax, S.llw, wvno, S.omega)
                                      : swd_dltar4(lay, S.mmax, S.llw, wvno, S.omega);
         nc++;
-        swd_control(S, del);
+        swd_control(S, del, nv);
     }
     if (ncalls) *ncalls = nc;
 }

@@ -176,14 +176,294 @@ __device__ __forceinline__ void swd_team_chain_ray5(const Lay &lay, int lane, co
 
 // Feed the round's values to the search in order; stop at the first one that ends the scan.
 // Returns the number of values the reference would have computed (the rest was speculation).
-BH_DEV int swd_team_consume(SwdState &S, int nt, const double *trials, const double *dels)
+template <class Nev>
+BH_DEV int swd_team_consume(SwdState &S, Nev &nv, int nt, const double *trials, const double *dels)
 {
     int used = 0;
     for (int j = 0; j < nt; j++) {
-        swd_control(S, dels[j]);
+        swd_control(S, dels[j], nv);
         used++;
         if (S.ev != SWD_EV_NONE || S.st != SWD_ST_B) break;
         if (j + 1 < nt && S.ceval != trials[j + 1]) break;   // cannot happen; guards the replay
+    }
+    return used;
+}
+
+// ================================================================================================
+// Wide teams (64*W lanes per search, swd_teamw_kernel): the lowest-latency form.
+//
+// Same two ideas as above, plus:
+//   * speculation across the end of a root search.  A period's search ends with ~8 sequential
+//     Neville / bisection evaluations (one trial each; surfdisp96.f:582-673) during which all lanes
+//     but L-1 idle.  Each of those rounds also evaluates, on the idle lanes, the START of the search
+//     that follows IF the current trial turns out to be the root: the entry evaluation of the next
+//     period (or of the second solve of a group-velocity pair) at c - 1.5 dc and the first grid points
+//     of its bracketing scan (surfdisp96.f:268-271,282-294,448-470).  In the round in which the root
+//     converges the next search is therefore already bracketed (or well on its way).
+//   * a value is only ever consumed for the (omega, c) it was computed at: the consuming loop
+//     matches every speculative trial against what the unchanged control code (swd_control /
+//     swd_driver) asks for next, bit for bit, and stops at the first mismatch.  The prediction can be
+//     wrong (reversed scan direction, no convergence yet, no root) -- it can never change a result.
+//   * the Dunkin chain of a trial runs on a QUAD of lanes (component i on lane i, the fifth on all
+//     four) with DPP quad permutes instead of LDS shuffles, matrices stored column-major so that a
+//     lane's column is one 48-byte run (kernels.hip).
+// Trials of a round are numbered 0..nt-1; trial j has its own (c, omega).
+enum { SWD_TEAMW_NT = 32 };       // max trials per round
+
+enum { SWD_MAT = 30 };            // doubles per stored layer matrix: 5 columns x 6 (5 used, 16-byte aligned)
+
+// ---- the plan of a round ----------------------------------------------------------------------
+// Slot 0 is the evaluation the search is waiting for; the rest is speculation, most valuable first:
+//   bracketing (ST_A / ST_B)   the scan continues on the grid: scan trial i = base + (i+1) dc by
+//                              repeated addition (surfdisp96.f:448-470), assuming the upward
+//                              direction getsol takes for normal dispersion
+//   refinement (ST_TOP / MID)  (1) the midpoints of the bracket this trial leaves: the next point if
+//                              the next step is a bisection (`half`, :620-640) -- 2 candidates, and the
+//                              4 of the step after it (about half of nevill's steps are bisections);
+//                              (2) the search that follows if this trial is the root: its entry
+//                              evaluation at c - 1.5 dc with the next period's omega (or the second
+//                              solve of a group-velocity pair, :268-271,:282-294) and its scan
+//   with >= 16 slots to spare  the midpoint of every scan cell: nevill's first point (:583) if the
+//                              sign change lies in that cell
+// The plan is a pure function of the (wave-uniform) state: swd_teamw_round lays the slots out,
+// swd_teamw_trial gives slot j's (c, omega) -- on the device lane j computes its own.  A slot whose
+// scan has left the search bounds is NaN (never matched).
+struct TeamwRound {
+    int nt;                       // slots in use
+    int nhalf;                    // 0, 2 or 6 bisection candidates in slots 1 .. nhalf
+    int entry;                    // slot of a successor search's entry evaluation, or -1
+    int scan0, stride, nscan;     // scan trial i in slot scan0 + i*stride, i < nscan (stride 2: cell
+                                  // midpoints in between)
+    double base, oms;             // the point the scan steps away from, omega of the scan
+};
+
+BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, const double *BH_RESTRICT per,
+                                  int cap)
+{
+    const double dc = (double)0.005f;
+    TeamwRound R;
+    R.nt = 1; R.nhalf = 0; R.entry = -1; R.scan0 = 1; R.stride = 1; R.nscan = 0;
+    R.base = S.ceval; R.oms = S.omega;
+    if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
+    if (cap <= 1) return R;
+    double clows;
+    bool scan_ok;
+    if (S.st == SWD_ST_A) {
+        clows = S.clow;
+        scan_ok = true;
+    } else if (S.st == SWD_ST_B) {
+        // slot 0 is itself a scan point: the step from S.c1
+        clows = S.clow;
+        R.base = S.c1;
+        R.scan0 = 0;
+        scan_ok = S.idir > 0 && S.c1 + dc == S.ceval;
+    } else {
+        if (cap >= 4) R.nhalf = cap >= 12 ? 6 : 2;
+        R.nt = 1 + R.nhalf;
+        R.scan0 = R.nt + 1;
+        if (R.nt >= cap || tg.mode != 1 || S.iq != 1 || S.ceval > (double)S.betmx) return R;
+        // which search follows if this trial is the root?  (mirror of swd_driver; only the plain
+        // case -- fundamental mode, no workspace -- is predicted)
+        const double TWOPI = 2.0 * 3.141592653589793, one = 1.0e-2, onea = 1.5;
+        const float h = 0.005f;
+        if (tg.igr > 0 && S.pass == 0) {            // second solve of the pair, surfdisp96.f:282-294
+            R.oms = TWOPI / (double)S.t1b;
+            R.base = S.ceval - onea * dc;
+            clows = 0.0 + one * dc;
+        } else {                                    // next period, surfdisp96.f:231-239,268-271
+            const int k2 = S.k + 1;
+            if (k2 > tg.nper || k2 >= S.ift) return R;
+            double t1 = per[k2 - 1];
+            if (tg.igr > 0) t1 = (double)(float)(t1 / (double)(1.f + h));
+            R.oms = TWOPI / t1;
+            R.base = ((S.pass == 0) ? S.ceval : S.ck) - onea * dc;
+            clows = S.cc;
+        }
+        R.entry = R.nt++;
+        scan_ok = true;
+    }
+    // the scan is only laid out in its plain form: upwards, never turned around at clow
+    // (swd_bracket_next resets c1 to clow when c1 + dc <= clow)
+    if (!scan_ok || !(R.base + dc > clows)) { if (R.scan0 == 0) R.scan0 = 1; return R; }
+    const int room = cap - (R.scan0 == 0 ? 0 : R.nt);
+    if (room <= 0) return R;
+    R.stride = room >= 16 ? 2 : 1;
+    R.nscan = (room + R.stride - 1) / R.stride;     // stride 2 and odd room: the last cell has no midpoint
+    R.nt = (R.scan0 == 0 ? 0 : R.nt) + room;
+    return R;
+}
+
+// Slot j of the round: (c, omega).  NaN marks a scan slot beyond the search bounds.
+BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, double *c, double *om)
+{
+    const double dc = (double)0.005f;
+    *c = S.ceval; *om = S.omega;
+    if (j <= 0) return;
+    if (j <= R.nhalf) {
+        const double ha = 0.5 * (S.c1 + S.ceval), hb = 0.5 * (S.ceval + S.c2);
+        const double lo = j == 3 ? S.c1 : j == 4 ? ha : j == 5 ? S.ceval : hb;
+        const double hi = j == 3 ? ha : j == 4 ? S.ceval : j == 5 ? hb : S.c2;
+        *c = j == 1 ? ha : j == 2 ? hb : 0.5 * (lo + hi);
+        return;
+    }
+    *om = R.oms;
+    if (j == R.entry) { *c = R.base; return; }
+    const int q = j - R.scan0;
+    const int i = R.stride == 2 ? q >> 1 : q;        // scan cell
+    const bool mid = R.stride == 2 && (q & 1);
+    // base_0 = base, base_{n+1} = c_n = base_n + dc by repeated addition.  The scan stops at the first
+    // base outside [cc, cfail) (swd_control: "c1 < cm or c1 >= betmx + dc -> no root"); the bases
+    // increase, so it is enough to look at the first and at this cell's
+    double b = R.base, cn = R.base + dc;
+    int n = i;
+    for (; n >= 4; n -= 4) {
+        const double c1 = cn + dc, c2 = c1 + dc, c3 = c2 + dc;
+        b = c3;
+        cn = c3 + dc;
+    }
+    if (n & 2) {
+        const double c1 = cn + dc;
+        b = c1;
+        cn = c1 + dc;
+    }
+    if (n & 1) {
+        b = cn;
+        cn = b + dc;
+    }
+    const bool ok = !(R.base < S.cc) && !(b >= S.cfail);
+    *c = ok ? (mid ? 0.5 * (b + cn) : cn) : __builtin_nan("");
+}
+
+// Stores a Rayleigh layer matrix column by column (column i at p + 6 i: ca(1..5, i)).
+BH_DEV void swd_teamw_store_dunkin(double *p, const Dunkin &a)
+{
+    p[0] = a.c11; p[1] = a.c21; p[2] = a.c31; p[3] = a.c41; p[4] = a.c51;
+    p[6] = a.c12; p[7] = a.c22; p[8] = a.c32; p[9] = a.c42; p[10] = a.c41;
+    p[12] = a.c13; p[13] = a.c23; p[14] = a.c33; p[15] = a.c43; p[16] = a.c53;
+    p[18] = a.c14; p[19] = a.c24; p[20] = a.c34; p[21] = a.c22; p[22] = a.c21;
+    p[24] = a.c15; p[25] = a.c14; p[26] = a.c35; p[27] = a.c12; p[28] = a.c11;
+}
+BH_DEV void swd_teamw_load_dunkin(const double *p, Dunkin &a)
+{
+    a.c11 = p[0]; a.c21 = p[1]; a.c31 = p[2]; a.c41 = p[3]; a.c51 = p[4];
+    a.c12 = p[6]; a.c22 = p[7]; a.c32 = p[8]; a.c42 = p[9];
+    a.c13 = p[12]; a.c23 = p[13]; a.c33 = p[14]; a.c43 = p[15]; a.c53 = p[16];
+    a.c14 = p[18]; a.c24 = p[19]; a.c34 = p[20];
+    a.c15 = p[24]; a.c35 = p[26];
+}
+
+// Layer matrix of layer r (0-based above llw) for the trial (c, omega) into slot `p`.
+template <class Lay>
+BH_DEV void swd_teamw_assemble_one(const Lay &lay, int ifunc, const SwdState &S, int r, double c, double om,
+                                   double *p)
+{
+    const int i0 = S.llw - 1 + r;
+    const double wvno = om / c;
+    if (ifunc == 1) {
+        LoveLayer o;
+        swd_love_layer(lay, i0, wvno, om, o);
+        p[0] = o.cosq; p[1] = o.y; p[2] = o.z; p[3] = o.xmu;
+    } else {
+        double omega = om;
+        if (omega < 1.0e-4) omega = 1.0e-4;
+        Dunkin a;
+        swd_ray_layer_matrix(lay, i0, wvno, wvno * wvno, omega, a);
+        swd_teamw_store_dunkin(p, a);
+    }
+}
+
+// Period-equation value of the trial (c, omega) from its nlm assembled layer matrices at `m0`
+// (generic form: one lane per trial; the device runs Rayleigh trials on quads, kernels.hip).
+template <class Lay>
+BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, double c, double om,
+                                  const double *m0)
+{
+    const int nlm = S.mmax - S.llw;
+    const double wvno = om / c;
+    if (ifunc == 1) {
+        double e1, e2;
+        swd_love_halfspace(lay, S.mmax, wvno, om, e1, e2);
+        for (int r = nlm - 1; r >= 0; r--) {
+            const double *p = m0 + (long)r * SWD_MAT;
+            LoveLayer o;
+            o.cosq = p[0]; o.y = p[1]; o.z = p[2]; o.xmu = p[3];
+            swd_love_apply(e1, e2, o);
+        }
+        return e1;
+    }
+    double omega = om;
+    if (omega < 1.0e-4) omega = 1.0e-4;
+    double e[5];
+    swd_ray_halfspace(lay, S.mmax, wvno, wvno * wvno, omega, e);
+    for (int r = nlm - 1; r >= 0; r--) {
+        Dunkin a;
+        swd_teamw_load_dunkin(m0 + (long)r * SWD_MAT, a);
+        swd_dunkin_apply(e, a);
+    }
+    return (S.llw != 1) ? swd_ray_water(lay, wvno, omega, e) : e[0];
+}
+
+// Feeds the round's values to the search: a trial is consumed iff the search asks for exactly its
+// (omega, c) next.  When a root search ends inside the round the driver runs here (results stored,
+// next period / second solve / next mode set up) and matching goes on with the speculative trials;
+// a task boundary (next model) ends the round.
+//   vals   `int find(double om, double c)`: slot computed at exactly that point, or -1;
+//          `double del(int j)`, `double c(int j)`: value and velocity of slot j;
+//          `int run(int i, bool neg)`: how many of the scan trials i, i+1, ... (valid ones, in a
+//          row) have a value whose sign bit equals `neg`;
+//          `probe(int)`, `count(int, int)`: cycle probes of the diagnostic build, else empty.
+// Scan trials without a sign change are the bulk of all evaluations (two thirds) and
+// each costs a pass through swd_control although all it does is "c1 = c2, del1 = del2, next grid
+// point" (surfdisp96.f:461-470): a run of them is taken in one step.
+// Returns the number of values consumed (= evaluations of the reference).
+template <class Lay, class Src, class Vals, class Nev>
+BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const SwdTargetDev &tg,
+                             const double *BH_RESTRICT per, int wss, const TeamwRound &R, const Vals &vals)
+{
+    const double dc = (double)0.005f;
+    int used = 0;
+    while (used < R.nt) {
+        const int j = vals.find(S.omega, S.ceval);
+        vals.probe(4);
+        if (j < 0) break;
+        if (S.st == SWD_ST_B && S.idir > 0 && R.nscan > 0 && j >= R.scan0) {
+            const int q = j - R.scan0, i = q / R.stride;
+            if (q == i * R.stride && i < R.nscan) {
+                int m = vals.run(i, dsign1(S.del1) < 0.0);
+                if (m > SWD_MAX_BRACKET_STEPS - S.nbrk) m = 0;          // (the hard step cap: one by one)
+                if (m > 0) {
+                    // m steps of label 1000 without a sign change.  Every base of the run but the
+                    // last lies inside the bounds (else the following slots would be NaN).
+                    const int last = R.scan0 + (i + m - 1) * R.stride;
+                    S.del2 = vals.del(last);
+                    S.c1 = vals.c(last);
+                    S.del1 = S.del2;
+                    used += m;
+                    if (S.c1 < S.cc || S.c1 >= S.cfail) {
+                        S.nbrk += m - 1;
+                        S.ev = SWD_EV_NOROOT;
+                        swd_driver(S, lay, src, tg, per, wss, false);
+                        if (S.st == SWD_ST_DONE) break;
+                    } else {
+                        S.nbrk += m;
+                        S.c2 = swd_bracket_next(S.c1, S.idir, S.clow, dc);
+                        S.ceval = S.c2;
+                    }
+                    vals.probe(5);
+                    vals.count(10, 1);
+                    continue;
+                }
+            }
+        }
+        swd_control(S, vals.del(j), nv);
+        used++;
+        vals.probe(6);
+        vals.count(11, 1);
+        if (S.ev != SWD_EV_NONE) {
+            swd_driver(S, lay, src, tg, per, wss, false);
+            vals.probe(7);
+            if (S.st == SWD_ST_DONE) break;          // task finished: the next model is fetched by the caller
+        }
     }
     return used;
 }

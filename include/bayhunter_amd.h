@@ -98,6 +98,8 @@ size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets)
 #define BH_SWD_TEAM32 3 /* 32 lanes per search, two searches per wave                               */
 #define BH_SWD_TEAM16 4 /* 16 lanes per search, four per wave: less speculation, more searches/s   */
 #define BH_SWD_TEAM8 5  /* 8 lanes per search, eight per wave: layer-parallel assembly only         */
+#define BH_SWD_TEAM128 6 /* 2 waves per search: deeper speculation for deep models / few searches   */
+#define BH_SWD_TEAM256 7 /* 4 waves per search                                                      */
 int bh_swd_set_kernel(int mode);
 int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                  const double *vp, const double *vs, const double *rho, int ntargets,

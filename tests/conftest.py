@@ -52,6 +52,8 @@ def _wrap_hostsim(hs):
     hs.hs_surfdisp96_team.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, dp, dp, C.c_int, C.POINTER(C.c_long),
                                       C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    hs.hs_surfdisp96_teamw.restype = C.c_int
+    hs.hs_surfdisp96_teamw.argtypes = hs.hs_surfdisp96_team.argtypes
     hs.hs_rf.restype = C.c_int
     hs.hs_rf.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int,
                          C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp]
@@ -71,13 +73,14 @@ def _wrap_hostsim(hs):
             return cg, e, nc.value
 
         @staticmethod
-        def swd_team(h, vp, vs, rho, per, iw, ig, mode=1, fl=0, nlanes=64):
+        def swd_team(h, vp, vs, rho, per, iw, ig, mode=1, fl=0, nlanes=64, wide=False):
             f = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32))
                  for x in (h, vp, vs, rho)]
             t = np.ascontiguousarray(per, dtype=np.float64)
             cg = np.zeros(len(t))
             nc, ns, nr = C.c_long(0), C.c_long(0), C.c_long(0)
-            e = hs.hs_surfdisp96_team(*[x.ctypes.data_as(fp) for x in f], len(h), fl, iw, mode, ig,
+            fn = hs.hs_surfdisp96_teamw if wide else hs.hs_surfdisp96_team
+            e = fn(*[x.ctypes.data_as(fp) for x in f], len(h), fl, iw, mode, ig,
                                       len(t), t.ctypes.data_as(dp), cg.ctypes.data_as(dp), nlanes,
                                       C.byref(nc), C.byref(ns), C.byref(nr))
             return cg, e, nc.value, ns.value, nr.value

@@ -40,6 +40,7 @@ struct OneTask {
         return nlayer;
     }
     void done(int e) { err = e; }
+    void sphere(HostLay &lay, int mmax, int ifunc) { bh::swd_sphere(lay, mmax, ifunc); }
 };
 }  // namespace
 
@@ -76,6 +77,8 @@ extern "C" int hs_surfdisp96_team(const float *thkm, const float *vpm, const flo
            *dels = trials + bh::SWD_TEAM_NT;
     bh::SwdState S;
     bh::swd_state_init(S);
+    bh::NevRegs nv;
+    bh::swd_nev_init(nv);
     long nc = 0, ns = 0, nr = 0;
     for (;;) {
         bh::swd_driver(S, lay, src, tg, t, 1);
@@ -85,7 +88,85 @@ extern "C" int hs_surfdisp96_team(const float *thkm, const float *vpm, const flo
             bh::swd_team_assemble(lay, lane, nlanes, iwave, S, nt, trials, mats);
         for (int lane = 0; lane < nlanes; lane++)
             bh::swd_team_chain(lay, lane, iwave, S, nt, trials, mats, dels);
-        nc += bh::swd_team_consume(S, nt, trials, dels);
+        nc += bh::swd_team_consume(S, nv, nt, trials, dels);
+        ns += nt;
+        nr++;
+    }
+    if (ncalls) *ncalls = nc;
+    if (nspec) *nspec = ns;
+    if (nrounds) *nrounds = nr;
+    return src.err;
+}
+
+// CPU replay of the wide-team kernel (swd_teamw_kernel): speculation across the end of a root search,
+// values consumed by (omega, c) match.  `nlanes` = 64 * W virtual lanes.
+namespace {
+struct ArrayVals {
+    const double *tc, *tom, *dl;
+    const bh::TeamwRound *R;
+    int find(double om, double c) const
+    {
+        for (int j = 0; j < R->nt; j++)
+            if (tom[j] == om && tc[j] == c) return j;
+        return -1;
+    }
+    double del(int j) const { return dl[j]; }
+    double c(int j) const { return tc[j]; }
+    void probe(int) const {}
+    void count(int, int) const {}
+    int run(int i, bool neg) const
+    {
+        int m = 0;
+        for (; i + m < R->nscan; m++) {
+            const int j = R->scan0 + (i + m) * R->stride;
+            if (j >= R->nt || tc[j] != tc[j] || std::signbit(dl[j]) != neg) break;
+        }
+        return m;
+    }
+};
+}  // namespace
+extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                                   int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                                   const double *t, double *cg, int nlanes, long *ncalls, long *nspec,
+                                   long *nrounds)
+{
+    std::vector<float> d(thkm, thkm + nlayer), a(vpm, vpm + nlayer), b(vsm, vsm + nlayer),
+        r(rhom, rhom + nlayer);
+    HostLay lay{nullptr, nullptr, nullptr, nullptr};
+    bh::SwdTargetDev tg{iwave, igr, mode, iflsph, kmax, 0, 0, 0};
+    std::vector<double> cws(kmax > 0 ? kmax : 1), cbws(kmax > 0 ? kmax : 1);
+    OneTask src{HostLay{d.data(), a.data(), b.data(), r.data()}, nlayer, 0, -1, cg, cws.data(), cbws.data()};
+    const int NT = bh::SWD_TEAMW_NT;
+    std::vector<double> mats((size_t)(nlanes > nlayer ? nlanes : nlayer) * bh::SWD_MAT), tc(NT), tom(NT), dl(NT);
+    bh::SwdState S;
+    bh::swd_state_init(S);
+    double nx[12], ny[12];
+    bh::NevMem nv{nx, ny};
+    bh::swd_nev_init(nv);
+    long nc = 0, ns = 0, nr = 0;
+    for (;;) {
+        bh::swd_driver(S, lay, src, tg, t, 1);
+        if (S.st == bh::SWD_ST_DONE) break;
+        const int nlm = S.mmax - S.llw;
+        int cap = nlm > 0 ? nlanes / nlm : NT;
+        if (cap > nlanes / 4) cap = nlanes / 4;           // one quad per Rayleigh trial
+        const bh::TeamwRound R = bh::swd_teamw_round(S, tg, t, cap);
+        const int nt = R.nt;
+        if (nt < 1 || nt > NT || nt > (cap > 1 ? cap : 1)) return -100;      // layout invariants
+        for (int j = 0; j < nt; j++) bh::swd_teamw_trial(R, S, j, &tc[j], &tom[j]);
+        if (tc[0] != S.ceval || tom[0] != S.omega) return -101;
+        for (int i = 0; i + 1 < R.nscan; i++) {           // scan trials: consecutive grid points
+            const int j0 = R.scan0 + i * R.stride, j1 = j0 + R.stride;
+            if (j1 < nt && tc[j1] == tc[j1] && tc[j1] != tc[j0] + (double)0.005f) return -102;
+        }
+        for (int j = 0; j < nt; j++) {
+            if (tc[j] != tc[j]) { dl[j] = 0.0; continue; }                    // NaN slot: not evaluated
+            for (int rr = 0; rr < nlm; rr++)
+                bh::swd_teamw_assemble_one(lay, iwave, S, rr, tc[j], tom[j], mats.data() + ((size_t)j * nlm + rr) * bh::SWD_MAT);
+            dl[j] = bh::swd_teamw_chain_one(lay, iwave, S, tc[j], tom[j], mats.data() + (size_t)j * nlm * bh::SWD_MAT);
+        }
+        ArrayVals vals{tc.data(), tom.data(), dl.data(), &R};
+        nc += bh::swd_teamw_consume(S, nv, lay, src, tg, t, 1, R, vals);
         ns += nt;
         nr++;
     }

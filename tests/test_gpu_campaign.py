@@ -71,7 +71,7 @@ def test_lvz_sets_2048(lib, oracle, L):
     assert np.nanmax(np.abs(out[:, eng.slices[4]] - wrf)) <= TOL_RF * max(1.0, np.nanmax(np.abs(wrf)))
 
 
-@pytest.mark.parametrize('kernel', ['auto', 'lane', 'team', 'team32', 'team16', 'team8'])
+@pytest.mark.parametrize('kernel', ['auto', 'lane', 'team', 'team128', 'team32', 'team16', 'team8'])
 def test_cfg2_exact_shape(lib, oracle, kernel):
     """BASELINE.json configs[1]: Rayleigh phase only, 5 layers, 20 periods, 1 024 models (bench.py
     --workload cfg2, its seed)."""
@@ -94,7 +94,7 @@ def test_cfg2_shape_with_lvz(lib, oracle):
     _check_swd('rdispph', out, want, err[:, 0], werr, min_identical=MIN_IDENTICAL_LVZ)
 
 
-@pytest.mark.parametrize('kernel', ['auto', 'lane', 'team', 'team8'])
+@pytest.mark.parametrize('kernel', ['auto', 'lane', 'team', 'team128', 'team256', 'team8'])
 def test_cfg4_exact_shape(lib, oracle, kernel):
     """BASELINE.json configs[3], one GPU's share: Rayleigh phase (21 periods) + P receiver function,
     15 layers, 64 models (bench.py --workload cfg4, its seed)."""
@@ -134,7 +134,7 @@ def test_cfg5_ragged_full_size(lib, oracle):
     assert np.abs(out[:, 21:] - oracle.rf_batch(H, VP, VS, RHO, nl, nthreads=THREADS)).max() <= TOL_RF
 
 
-@pytest.mark.parametrize('kernel', ['lane', 'team', 'team32', 'team16', 'team8'])
+@pytest.mark.parametrize('kernel', ['lane', 'team', 'team256', 'team32', 'team16', 'team8'])
 @pytest.mark.parametrize('tag', ['L5_sorted', 'L5_lvz', 'L10_sorted', 'L10_lvz'])
 def test_water_layer_golden(lib, golden, tag, kernel):
     """vs[0] = 0 -> llw = 2: the layer loop stops above the water layer and the tail of dltar4

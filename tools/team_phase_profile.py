@@ -30,16 +30,16 @@ def main():
     from bayhunter_amd.synthetic import draw_models
     lib = _lib.load()
     lib.bh_debug_team_profile.argtypes = [C.c_void_p, C.c_int]
-    names = ['driver', 'plan', 'assemble', 'chain', 'consume']
+    names = ['driver', 'plan', 'assemble', 'chain', 'find+rest', 'fastfwd', 'control', 'driver2']
     print('# %s' % torch.cuda.get_device_name(0))
-    for L, P, B, mode in ((5, 20, 1024, 'team'), (10, 21, 1024, 'team'), (15, 21, 64, 'team'), (15, 21, 1024, 'team')):
+    for L, P, B, mode in ((5, 20, 1024, 'team'), (10, 21, 256, 'team128'), (15, 21, 64, 'team'), (15, 21, 64, 'team256')):
         H, VP, VS, RHO, nl = draw_models(B, L, seed=100 + L)
         eng = ForwardEngine(swd=[SwdSpec('rdispph', np.linspace(1, 41, P))])
         dm = eng.upload(H, VP, VS, RHO, nl)
         _lib.set_swd_kernel(mode)
         eng.run(dm)
         torch.cuda.synchronize()
-        buf = (C.c_ulonglong * 8)()
+        buf = (C.c_ulonglong * 16)()
         lib.bh_debug_team_profile(buf, 1)
         t0 = time.perf_counter()
         for _ in range(5):
@@ -48,13 +48,15 @@ def main():
         ms = (time.perf_counter() - t0) / 5 * 1e3
         lib.bh_debug_team_profile(buf, 1)
         v = np.array(list(buf), dtype=np.float64)
-        nsearch, rounds = v[7], v[6]
-        print('L=%d P=%d B=%d: %.3f ms per call, %.1f rounds per search (%.1f per period)'
-              % (L, P, B, ms, rounds / nsearch, rounds / nsearch / P))
-        tot = v[:5].sum()
+        nsearch, rounds = v[15], v[14]
+        print('%s L=%d P=%d B=%d: %.3f ms per call, %.1f rounds per search (%.1f per period)'
+              % (mode, L, P, B, ms, rounds / nsearch, rounds / nsearch / P))
+        tot = v[:8].sum()
         for i, n in enumerate(names):
             print('   %-9s %8.0f cycles per round  (%4.1f %%)' % (n, v[i] / rounds, 100 * v[i] / tot))
-        print('   total     %8.0f cycles per round, %.0f cycles per search' % (tot / rounds, tot / nsearch))
+        print('   total     %8.0f cycles per round, %.0f cycles per search; consumed %.2f of %.2f trials per round'
+              % (tot / rounds, tot / nsearch, v[8] / rounds, v[9] / rounds))
+        print('   per round: %.2f fast-forward steps, %.2f control calls' % (v[10] / rounds, v[11] / rounds))
     _lib.set_swd_kernel('auto')
 
 
