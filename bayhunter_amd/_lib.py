@@ -173,10 +173,10 @@ def check(rc):
 
 
 def set_swd_kernel(mode):
-    """'auto' | 'lane' | 'team' | 'team32' | 'team16' | 'team8' | 'team128' | 'team256'
+    """'auto' | 'lane' | 'team' | 'team32' | 'team16' | 'team8' | 'team128' | 'team256' | 'team512'
     (include/bayhunter_amd.h, bh_swd_set_kernel)."""
     check(load().bh_swd_set_kernel({'auto': 0, 'lane': 1, 'team': 2, 'team32': 3, 'team16': 4, 'team8': 5,
-                                    'team128': 6, 'team256': 7}[mode]))
+                                    'team128': 6, 'team256': 7, 'team512': 8}[mode]))
 
 
 def device_count():

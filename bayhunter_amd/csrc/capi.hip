@@ -211,7 +211,7 @@ int bh_set_device(int device)
 
 int bh_swd_set_kernel(int mode)
 {
-    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM256) return fail_arg("unknown kernel mode");
+    if (mode < BH_SWD_AUTO || mode > BH_SWD_TEAM512) return fail_arg("unknown kernel mode");
     g_swd_mode.store(mode, std::memory_order_relaxed);
     return BH_OK;
 }
@@ -272,51 +272,54 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     rc = get_queue_slot(&A.counters, &slot, &resident);
     if (rc) return rc;
     const int swd_mode = g_swd_mode.load(std::memory_order_relaxed);
-    // Few searches: spend a whole wave on each (swd_team.h, ~10x lower latency); many: one lane
-    // each (swd_lane, ~5x more searches per second).  bh_swd_set_kernel overrides.
-    // Which kernel: a small cost model fitted to profiles/r01_team_widths.txt (3-15 layers).  A team
-    // kernel with w lanes per search keeps cus * min(8, 160 KiB / LDS per wave) waves resident, 64/w
-    // searches each (`fit`); up to that many searches a call takes one search latency, which is
-    // (relative to the 64-lane team, w = 64 / 32 / 16 / 8) 1 / 1.7 / 2.9 / 3.4 around ten layers, where
-    // speculation pays most, 1 / 1.5 / 1.7 / 2.2 for shallow models (Lmax <= 6) and 1 / 1.9 / 2.1 / 2.4
-    // for deep ones (Lmax > 12); beyond `fit` the cost grows in proportion (the teams pull further
-    // searches from the queue).  The lane kernel takes 4.6 (4.2, 5.2) on that scale up to its own
-    // residency (cus * 8 waves * 64 lanes).  BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
+    // Which kernel: each form k has a latency lat_k (one search, chip mostly idle) and a saturation
+    // rate thr_k (searches per ms with every SIMD busy); a call with s searches costs about
+    // max(lat_k, s / thr_k).  Table measured on MI355X (256 CUs) for 21 periods, Rayleigh phase
+    // (profiles/r02_team_widths.txt; relative order is what matters), by deepest model of the batch;
+    // thr scales with the CU count.  Wide teams (64 W lanes, speculation across root searches) win up
+    // to a few thousand searches, 8-lane teams in the ten-thousands, the lane kernel beyond.
+    // bh_swd_set_kernel overrides; BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
     const long searches = (long)B * ntargets;
     const long cus = resident > 0 ? resident / 8 : 256;
-    const double lane_fit = (double)(cus * 8 * 64);
-    const int regime = Lmax <= 6 ? 0 : Lmax <= 12 ? 1 : 2;
-    static const double lane_latency[3] = {4.2, 4.6, 5.2};
-    double best = cus > 0 ? lane_latency[regime] * (searches > lane_fit ? searches / lane_fit : 1.0) : 0.0;
+    struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
+    static const Form forms[8] = {
+        {0,   {4.6, 6.8, 11.5, 16.0, 31.0},  {19500, 12850, 7280, 5020, 3250}},     // lane kernel
+        {8,   {2.7, 3.9, 6.8, 8.0, 14.0},    {4830, 3127, 1870, 1196, 640}},
+        {16,  {2.15, 2.9, 5.7, 7.0, 12.5},   {2980, 2167, 1274, 993, 770}},
+        {32,  {1.7, 2.2, 3.25, 4.7, 11.4},   {2050, 1520, 1014, 682, 595}},
+        {64,  {0.86, 0.88, 1.3, 1.77, 4.0},  {2240, 2000, 1290, 922, 760}},
+        {128, {0.75, 0.79, 1.0, 1.45, 2.4},  {1200, 1145, 840, 580, 470}},
+        {256, {0.77, 0.83, 0.95, 1.2, 2.0},  {650, 605, 490, 393, 313}},
+        {512, {0.89, 0.95, 1.15, 1.35, 2.05}, {330, 295, 234, 201, 168}},
+    };
+    const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
     bool team = false;
     int width = 64, team_resident = resident;
-    static const int widths[4] = {64, 32, 16, 8};
-    static const double team_latency[3][4] = {{1.0, 1.5, 1.7, 2.2}, {1.0, 1.7, 2.9, 3.4}, {1.0, 1.9, 2.1, 2.4}};
-    const double *latency = team_latency[regime];
-    long waves_of[4];
-    for (int i = 0; i < 4; i++) {
-        long per_cu = (long)(160 * 1024 / bh::swd_team_lds_bytes(Lmax, widths[i]));
-        waves_of[i] = cus * (per_cu > 8 ? 8 : per_cu);
-    }
-    if (cus > 0 && (team_threshold() <= 0 || searches <= team_threshold())) {
-        for (int i = 0; i < 4; i++) {
-            const double fit = (double)(waves_of[i] * (64 / widths[i]));
-            if (fit < 1) continue;
-            const double cost = latency[i] * (searches > fit ? searches / fit : 1.0);
-            if (cost < best) { best = cost; team = true; width = widths[i]; team_resident = (int)waves_of[i]; }
+    double best = 1e300;
+    for (int k = 0; k < 8; k++) {
+        const Form &f = forms[k];
+        if (f.width > 0) {
+            if (team_threshold() > 0 && searches > team_threshold()) continue;
+            if (bh::swd_team_lds_bytes(Lmax, f.width) > 160 * 1024) continue;
         }
+        const double thr = f.thr[regime] * (double)cus / 256.0;
+        const double cost = std::fmax(f.lat[regime], (double)searches / thr);
+        if (cost < best) { best = cost; team = f.width > 0; width = f.width > 0 ? f.width : 64; }
     }
+    auto narrow_resident = [&](int w) {       // persistent waves of a narrow-team kernel that stay resident
+        long per_cu = (long)(160 * 1024 / bh::swd_team_lds_bytes(Lmax, w));
+        long waves = cus * (per_cu > 8 ? 8 : per_cu);
+        return (int)(waves > 0 ? waves : 1);
+    };
     if (swd_mode == BH_SWD_LANE) team = false;
-    if (swd_mode == BH_SWD_TEAM128 || swd_mode == BH_SWD_TEAM256) {
+    else if (swd_mode >= BH_SWD_TEAM) {
         team = true;
-        width = swd_mode == BH_SWD_TEAM128 ? 128 : 256;
-    } else if (swd_mode >= BH_SWD_TEAM) {
-        team = true;
-        const int i = swd_mode == BH_SWD_TEAM8 ? 3 : swd_mode == BH_SWD_TEAM16 ? 2 : swd_mode == BH_SWD_TEAM32 ? 1 : 0;
-        width = widths[i];
-        team_resident = waves_of[i] > 0 ? (int)waves_of[i] : 1;
+        width = swd_mode == BH_SWD_TEAM8 ? 8 : swd_mode == BH_SWD_TEAM16 ? 16 : swd_mode == BH_SWD_TEAM32 ? 32
+              : swd_mode == BH_SWD_TEAM128 ? 128 : swd_mode == BH_SWD_TEAM256 ? 256
+              : swd_mode == BH_SWD_TEAM512 ? 512 : 64;
     }
-    if (team && bh::swd_team_lds_bytes(Lmax, width) > 160 * 1024) { team = true; width = 64; }   // 100 layers x 256 lanes
+    while (team && width > 64 && bh::swd_team_lds_bytes(Lmax, width) > 160 * 1024) width /= 2;
+    if (team && width < 64) team_resident = narrow_resident(width);
     hipError_t le = team ? bh::launch_swd_team(A, width, team_resident, (hipStream_t)stream)
                          : bh::launch_swd(A, resident, (hipStream_t)stream);
     rc = release_queue_slot(slot, (hipStream_t)stream);    // also after a failed launch: the slot is free

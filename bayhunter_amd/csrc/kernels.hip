@@ -478,6 +478,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
 __global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A) { swd_teamw_body<1>(A); }
 __global__ __launch_bounds__(2 * SWD_T) void swd_team128_kernel(SwdArgs A) { swd_teamw_body<2>(A); }
 __global__ __launch_bounds__(4 * SWD_T) void swd_team256_kernel(SwdArgs A) { swd_teamw_body<4>(A); }
+__global__ __launch_bounds__(8 * SWD_T) void swd_team512_kernel(SwdArgs A) { swd_teamw_body<8>(A); }
 
 // -------------------------------------------------------------------------------------------- RF
 // bit reversal (+ 1/sqrt(n)) and radix-2 butterflies of Mb buffers in LDS; all threads of the group
@@ -624,17 +625,17 @@ size_t swd_team_lds_bytes(int Lmax, int team)
 
 static int team_index(int team)
 {
-    return team == 8 ? 0 : team == 16 ? 1 : team == 32 ? 2 : team == 128 ? 4 : team == 256 ? 5 : 3;
+    return team == 8 ? 0 : team == 16 ? 1 : team == 32 ? 2 : team == 128 ? 4 : team == 256 ? 5 : team == 512 ? 6 : 3;
 }
 
 hipError_t launch_swd_team(const SwdArgs &A, int team, int resident_waves, hipStream_t stream)
 {
-    if (team != 8 && team != 16 && team != 32 && team != 128 && team != 256) team = 64;
+    if (team != 8 && team != 16 && team != 32 && team != 128 && team != 256 && team != 512) team = 64;
     size_t lds = swd_team_lds_bytes(A.Lmax, team);
-    static size_t lds_set[6][16] = {{0}, {0}, {0}, {0}, {0}, {0}};
+    static size_t lds_set[7][16] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}};
     void (*kern)(SwdArgs) = team == 8 ? swd_team8_kernel : team == 16 ? swd_team16_kernel
                           : team == 32 ? swd_team32_kernel : team == 128 ? swd_team128_kernel
-                          : team == 256 ? swd_team256_kernel : swd_team_kernel;
+                          : team == 256 ? swd_team256_kernel : team == 512 ? swd_team512_kernel : swd_team_kernel;
     hipError_t e = ensure_dyn_lds((const void *)kern, lds, lds_set[team_index(team)]);
     if (e != hipSuccess) return e;
     if (team >= SWD_T) {           // one workgroup per search; the hardware back-fills them

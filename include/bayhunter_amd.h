@@ -85,13 +85,17 @@ int  bh_set_device(int device);
  * err[b*ntargets + t]: the reference's err flag for that (model, target).
  * workspace: only needed when some target has mode > 1 (bh_swd_workspace_bytes). */
 size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets);
-/* Two kernels compute the same values: BH_SWD_LANE gives every lane its own search (throughput:
- * ~6.5e6 searches/s, ~14 ms latency), BH_SWD_TEAM spends a wave per search (speculative bracketing
- * + layer-parallel matrix assembly: ~10x lower latency, ~5x fewer searches/s); TEAM32/TEAM16 put
- * 2/4/8 searches on a wave (less speculation, more searches resident and per second).  BH_SWD_AUTO
- * (default) picks by a fitted cost model on searches per call, Lmax and the device's CU count
- * (typically: <= 2048 searches TEAM, <= 4096 TEAM32, <= 8192 TEAM16, <= ~22000 TEAM8, else LANE).
- * All of them return identical bits.  Process-wide setting. */
+/* Several kernels compute the same values, bit for bit:
+ *   BH_SWD_LANE     one search per lane (persistent lanes, work queue): the throughput form,
+ *                   ~7e6 ten-layer searches/s, ~12 ms latency
+ *   BH_SWD_TEAM     one wave (64 lanes) per search: speculative bracketing, layer-parallel matrix
+ *                   assembly, speculation across the end of a root search and on bisection steps
+ *                   (swd_team.h): ~1.3 ms for up to ~1000 ten-layer searches
+ *   TEAM128/256/512 2, 4, 8 waves per search: deeper speculation for deep models / few searches
+ *   TEAM32/16/8     2, 4, 8 searches per wave: less speculation, more searches resident
+ * BH_SWD_AUTO (default) picks by a measured latency / saturation-rate table on searches per call,
+ * deepest model and CU count (capi.hip; profiles/r02_team_widths.txt).  Process-wide setting,
+ * read once per call. */
 #define BH_SWD_AUTO 0
 #define BH_SWD_LANE 1
 #define BH_SWD_TEAM 2   /* 64 lanes per search: lowest latency                                     */
@@ -100,6 +104,7 @@ size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets)
 #define BH_SWD_TEAM8 5  /* 8 lanes per search, eight per wave: layer-parallel assembly only         */
 #define BH_SWD_TEAM128 6 /* 2 waves per search: deeper speculation for deep models / few searches   */
 #define BH_SWD_TEAM256 7 /* 4 waves per search                                                      */
+#define BH_SWD_TEAM512 8 /* 8 waves per search: a handful of deep models                            */
 int bh_swd_set_kernel(int mode);
 int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                  const double *vp, const double *vs, const double *rho, int ntargets,

@@ -21,14 +21,14 @@ def run(B, L, refs, P, mode, reps=3):
     _lib.set_swd_kernel('auto')
     return (time.perf_counter() - t0) / reps * 1e3
 
-MODES = ('lane', 'team', 'team32', 'team16', 'team8', 'auto')
+MODES = ('lane', 'team', 'team32', 'team16', 'team8', 'team128', 'team256', 'team512', 'auto')
 QUICK = os.environ.get('SWEEP_QUICK')
 for L, refs, P in (((2, 31), ['rdispph'], 21), (3, ['rdispph'], 21), (5, ['rdispph'], 21), (10, ['rdispph'], 21), (15, ['rdispph'], 21),
                    (10, ['rdispph', 'rdispgr', 'ldispph', 'ldispgr'], 40)):
-    for B in (256, 1024, 2048, 4096, 6144, 8192, 12288, 16384, 20480, 24576, 32768, 65536, 131072):
+    for B in (64, 256, 512, 1024, 2048, 4096, 6144, 8192, 12288, 16384, 20480, 24576, 32768, 65536, 131072):
         if len(refs) == 4 and B > 16384: continue
         if QUICK and (B not in (4096, 8192, 16384, 32768) or L in (5, 15, 3)): continue
-        ts = [run(B, L, refs, P, m) for m in MODES]
+        ts = [run(B, L, refs, P, m) if not (m in ('team128', 'team256', 'team512') and B * len(refs) > 8192) else float('inf') for m in MODES]
         best = MODES[int(np.argmin(ts[:-1]))] + ('  auto within %.0f %% of best' % (100 * (ts[-1] / min(ts[:-1]) - 1)))
         print('L=%s targets=%d P=%d B=%6d  ' % (('%2d' % L) if isinstance(L, int) else 'ragged', len(refs), P, B) +
               '  '.join('%s %8.2f ms' % (m, t) for m, t in zip(MODES, ts)) + '  -> ' + best)
