@@ -387,20 +387,69 @@ class ChainPool(object):
                           rep(ch['noise'], True), rep(ch['vpvs'], False))
         return out
 
-    def gather(self, group=None):
-        """All ranks' sample blocks -> dict of [nchains_total, nmodels, ...] arrays on every rank
-        (+ 'naccepted').  The one exchange of a multi-GPU run (the reference keeps these blocks in
-        shared memory, src/mcmcOptimizer.py:77-125): fixed-shape all_gather over RCCL, or gloo."""
+    def gather(self, group=None, root=0, everywhere=False):
+        """All ranks' sample blocks -> dict of [nchains_total, nmodels, ...] arrays (+ 'naccepted') on
+        rank `root` (None on the others), or on every rank with everywhere=True.  The one exchange of
+        a multi-GPU run (the reference keeps these blocks in shared memory, src/mcmcOptimizer.py:
+        77-125): each rank sends its block once, point to point (distributed.gather_rows_to_root) --
+        RCCL over xGMI with backend "nccl", gloo on CPU.  Bytes per rank: nchains_local * nmodels *
+        (2*(maxlayers+1) + (ntargets+1) + 1 + 2*ntargets + 1 + 2) * 4 (iter is float64)."""
         import torch
         import torch.distributed as dist
-        from .distributed import gather_rows
+        from .distributed import gather_rows, gather_rows_to_root
         blocks = dict(models=self.models, misfits=self.misfits, likes=self.likes, noise=self.noise,
                       vpvs=self.vpvs, iter=self.iter, naccepted=self.counters()[0])
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not dist.is_initialized():
             return blocks
         dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else 'cpu'
-        return {k: gather_rows(torch.from_numpy(np.ascontiguousarray(v)).to(dev), self.nchains_total, group).cpu().numpy()
-                for k, v in blocks.items()}
+        out = {}
+        for k, v in blocks.items():
+            t = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+            g = gather_rows(t, self.nchains_total, group) if everywhere else \
+                gather_rows_to_root(t, self.nchains_total, root, group)
+            out[k] = None if g is None else g.cpu().numpy()
+        return None if out['likes'] is None else out
+
+    def final(self, i, maxmodels=None):
+        """What save() writes for chain i's main phase: residence-time weighted samples thinned to at
+        most `maxmodels` rows (SingleChain.py:646-663, :665-690), as float32 [rows, width] with the
+        columns models | misfits | likes | noise | vpvs -- or an empty array if nothing was accepted
+        after the burn-in."""
+        w = self.weighted(i)[2]
+        width = self.models.shape[2] + self.misfits.shape[2] + 1 + self.noise.shape[2] + 1
+        if w is None:
+            return np.zeros((0, width), dtype=np.float32)
+        maxmodels = maxmodels or self.initparams['maxmodels']
+        thin = int(np.ceil(float(w[1].size) / float(maxmodels)))
+        models, likes, misfits, noise, vpvs = (a[::thin] for a in w)
+        return np.concatenate([models, misfits, likes[:, None], noise, vpvs[:, None]], axis=1).astype(np.float32)
+
+    def gather_final(self, maxmodels=None, group=None, root=0):
+        """Thin BEFORE the exchange: every rank weights and thins its chains like save() does and
+        sends only those rows (<= maxmodels per chain; src/Plotting.py:198-219 keeps no more for the
+        merged posterior).  Rank `root` gets one float32 [rows, width] array per chain (global chain
+        order; columns as in `final`), the others None."""
+        import torch
+        import torch.distributed as dist
+        from .distributed import gather_ragged_to_root
+        mine = [self.final(i, maxmodels) for i in range(self.nchains)]
+        if not dist.is_initialized():
+            return mine
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else 'cpu'
+        width = mine[0].shape[1] if mine else 0
+        rows = np.array([m.shape[0] for m in mine], dtype=np.int64)
+        flat = np.concatenate(mine, axis=0) if mine else np.zeros((0, width), dtype=np.float32)
+        counts = gather_ragged_to_root(torch.from_numpy(rows).to(dev), root, group)
+        data = gather_ragged_to_root(torch.from_numpy(np.ascontiguousarray(flat)).to(dev), root, group)
+        if data is None:
+            return None
+        out = []
+        for c, d in zip(counts, data):
+            d, lo = d.cpu().numpy(), 0
+            for n in c.cpu().numpy():
+                out.append(d[lo:lo + int(n)])
+                lo += int(n)
+        return out
 
     def save(self, savepath=None, chainidx_offset=None):
         """Write <savepath>/data/c%03d_p{1,2}{models,likes,misfits,noise,vpvs}.npy like

@@ -485,11 +485,16 @@ __global__ __launch_bounds__(8 * SWD_T) void swd_team512_kernel(SwdArgs A) { swd
 __device__ __forceinline__ void rf_block_fft(double *S, int per_model, int Mb, int n, const RfLaunch &P,
                                              const double *tw, int tid)
 {
+#if !(defined(BH_RF_EXP) && BH_RF_EXP == 1)
     for (int idx = tid; idx < Mb * n; idx += RF_T) {
         int m = idx / n, i = idx - m * n;
         rf_fft_bitrev_scale(S + (long)m * per_model, n, P.log2n, P.sc, i);
     }
     __syncthreads();
+#endif
+#if defined(BH_RF_EXP) && BH_RF_EXP == 2
+    return;
+#endif
     for (int l = 1; l < n; l <<= 1) {
         for (int idx = tid; idx < Mb * (n / 2); idx += RF_T) {
             int m = idx / (n / 2), bf = idx - m * (n / 2);
@@ -539,7 +544,11 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     }
     __syncthreads();
     // P3: (model, frequency) tasks, model-major
+#if defined(BH_RF_EXP) && BH_RF_EXP == 3
+    const int ntask = 0;
+#else
     const int ntask = Mb * P.nact;
+#endif
     for (int task = tid; task < ntask; task += RF_T) {
         int m = task / P.nact, j = task - m * P.nact;
         int nl = A.nlay[b0 + m];

@@ -66,6 +66,12 @@ BH_HD RfLayout rf_layout(int Lmax, int nsamp)
     lo.off_sc = lo.off_coef + 32 * Lmax; // 16 scalars
     int need = lo.off_sc + 16;
     lo.per_model = need > 2 * nsamp ? need : 2 * nsamp;
+    // A wave of phase 3 that straddles two models reads the same offsets of both blocks.  With a block
+    // length that is a multiple of the bank row (2*nsamp doubles = 8 KiB) those pairs collide on every
+    // read; 16 bytes of padding put the second model's accesses four banks further.
+#if !defined(BH_RF_NO_PAD)
+    lo.per_model += 2;
+#endif
     return lo;
 }
 enum { RF_SC_H2 = 0, RF_SC_T0 = 8, RF_SC_M11 = 9, RF_SC_M12 = 10, RF_SC_M21 = 11, RF_SC_M22 = 12,

@@ -9,6 +9,12 @@ For every set-up in tests/scenarios/chain_scenario.py::CASES and three seeds the
 chain keeps: the accepted models, likelihoods, misfits, noise parameters, vp/vs (float32, as the
 reference stores them) and the iteration at which each was accepted.
 Output: chains_golden.npz (data only).
+
+For the 'tutorial' set-up with maxmodels = 150 the file chain_files_golden.npz additionally holds the
+ten result files the reference chain itself writes (SingleChain.save_finalmodels, src/SingleChain.py:
+646-690: c000_p{1,2}{models,likes,misfits,noise,vpvs}.npy -- residence-time weighting, thinning), one
+array per file under the file's name, so that the writer of the chain pool (ChainPool.save) can be
+compared with them where the reference tree does not exist.
 """
 import os
 import sys
@@ -46,6 +52,20 @@ def main():
                 out['%s/%d/%s' % (name, seed, k)] = np.asarray(res[k])
     np.savez_compressed(os.path.join(HERE, 'chains_golden.npz'), **out)
     print('wrote chains_golden.npz', os.path.getsize(os.path.join(HERE, 'chains_golden.npz')), 'bytes')
+    # the reference chain's own result files for one set-up
+    import tempfile
+    case = CASES['tutorial']
+    files = {'maxmodels': np.array(150), 'seed': np.array(case['seed'])}
+    with tempfile.TemporaryDirectory() as td:
+        rc.run_chain(None, refs=case.get('refs', ('rdispph', 'prf')), plugin_for=lambda ref, x: OraclePlugin(oracle, x, ref),
+                     seed=case['seed'], burnin=case['burnin'], main=case['main'], data_dir=data,
+                     priors=case['priors'], initparams=dict(case['initparams'], maxmodels=150), savepath=td)
+        names = sorted(f for f in os.listdir(os.path.join(td, 'data')) if f.endswith('.npy'))
+        assert len(names) == 10, names
+        for f in names:
+            files[f[:-4]] = np.load(os.path.join(td, 'data', f))
+    np.savez_compressed(os.path.join(HERE, 'chain_files_golden.npz'), **files)
+    print('wrote chain_files_golden.npz', sorted(k for k in files if k.startswith('c')))
 
 
 if __name__ == '__main__':

@@ -152,6 +152,23 @@ def test_storage_overflow_is_reported(oracle):
         make_pool(oracle, DATA, case, seeds=[3]).run()
 
 
+def test_result_files_equal_the_committed_reference_files(oracle, tmp_path):
+    """SURVEY 8(f4) without the reference tree: the ten files the reference's own chain writes for the
+    tutorial set-up (tests/golden/chain_files_golden.npz, made by make_golden_chains.py from the
+    unmodified SingleChain.save_finalmodels) against ChainPool.save(): dtype, shape and every value."""
+    want = np.load(os.path.join(os.path.dirname(DATA), 'chain_files_golden.npz'))
+    case = dict(CASES['tutorial'])
+    case['initparams'] = dict(case['initparams'], maxmodels=int(want['maxmodels']))
+    pool = make_pool(oracle, DATA, case, seeds=[int(want['seed'])]).run()
+    assert pool.save(str(tmp_path)) == 10
+    names = sorted(k for k in want.files if k.startswith('c000_'))
+    assert len(names) == 10
+    assert sorted(f[:-4] for f in os.listdir(str(tmp_path / 'data')) if f.endswith('.npy')) == names
+    for k in names:
+        a, b = want[k], np.load(str(tmp_path / 'data' / (k + '.npy')))
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=True), k
+
+
 @needs_ref
 def test_result_files_equal_the_reference_chains(oracle, tmp_path):
     case = CASES['tutorial']

@@ -114,3 +114,85 @@ def test_gloo_world2_chain_pool_shards_and_gathers(golden_chains):
         assert int(full['naccepted'][i]) == n
         for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
             assert np.array_equal(full[k][i, :n], golden_chains['fixednoise/%d/%s' % (seed, k)], equal_nan=True), (seed, k)
+
+
+# ---- gather to the root: ragged shards, nothing replicated, thinning before the exchange --------
+def _root_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from bayhunter_amd.distributed import gather_ragged_to_root, gather_rows_to_root
+    n = 5                                                   # 5 rows over 4 ranks: shards 2, 1, 1, 1
+    lo, hi = shard_range(n, rank, world)
+    rows = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)[lo:hi]
+    full = gather_rows_to_root(rows, n, dst=0)
+    rag = gather_ragged_to_root(torch.full((rank * 2, 2), float(rank)), dst=0)     # 0, 2, 4, 6 rows
+    from chain_scenario import CASES, joint_target
+    from bayhunter_amd.chains import ChainPool
+    case = CASES['fixednoise']
+    data = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
+    joint = joint_target(data, lambda xs, xr: (None, None))
+    rng = np.random.RandomState(1)
+
+    def ev(packed, nlay, noise):                            # made-up likelihood: only the plumbing is tested
+        return -60.0 * (packed[:, 2, 0] - 3.1) ** 2 - 1e-3 * nlay, np.zeros((packed.shape[0], 3))
+    ip = dict(case['initparams'], iter_burnin=60, iter_main=40, acceptance=(40, 100), maxmodels=17)
+    seeds = [5, 6, 7, 8, 9]
+    pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=seeds, shard=(rank, world),
+                     evaluator=ev).run()
+    blocks = pool.gather()
+    everywhere = pool.gather(everywhere=True)
+    final = pool.gather_final()
+    q.put((rank, None if full is None else full.numpy(), None if rag is None else [r.numpy() for r in rag],
+           pool.first, pool.nchains, blocks, everywhere['likes'], final))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world4_gather_to_root_ragged_and_thinned():
+    """5 chains on 4 ranks (2+1+1+1): only the root holds the gathered blocks; they equal a single
+    process's; gather_final delivers what save() would write, thinned to maxmodels rows per chain."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_root_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(4):
+        r = q.get(timeout=240)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full, rag = got[0][0], got[0][1]
+    assert np.array_equal(full, np.arange(15, dtype=np.float32).reshape(5, 3))
+    assert [a.shape for a in rag] == [(0, 2), (2, 2), (4, 2), (6, 2)] and all((a == i).all() for i, a in enumerate(rag))
+    assert [got[r][2:4] for r in range(4)] == [(0, 2), (2, 1), (3, 1), (4, 1)]
+    for r in (1, 2, 3):                                     # nothing is replicated onto the other ranks
+        assert got[r][0] is None and got[r][1] is None and got[r][4] is None and got[r][6] is None
+    # the same five chains in one process
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+    from chain_scenario import CASES, joint_target
+    from bayhunter_amd.chains import ChainPool
+    case = CASES['fixednoise']
+    joint = joint_target(os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed'), lambda xs, xr: (None, None))
+    ev = lambda packed, nlay, noise: (-60.0 * (packed[:, 2, 0] - 3.1) ** 2 - 1e-3 * nlay, np.zeros((packed.shape[0], 3)))
+    ip = dict(case['initparams'], iter_burnin=60, iter_main=40, acceptance=(40, 100), maxmodels=17)
+    one = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=[5, 6, 7, 8, 9], evaluator=ev).run()
+    blocks = got[0][4]
+    for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
+        assert np.array_equal(blocks[k], getattr(one, k), equal_nan=True), k
+    assert np.array_equal(blocks['naccepted'], one.counters()[0])
+    for r in range(4):
+        assert np.array_equal(got[r][5], one.likes, equal_nan=True)          # everywhere=True: all ranks
+    final = got[0][6]
+    assert len(final) == 5
+    for i in range(5):
+        want = one.final(i)
+        assert 0 < want.shape[0] <= 17 and np.array_equal(final[i], want, equal_nan=True)
+        w = one.weighted(i)[2]
+        thin = int(np.ceil(w[1].size / 17.0))
+        assert np.array_equal(want[:, :one.models.shape[2]], w[0][::thin].astype(np.float32), equal_nan=True)

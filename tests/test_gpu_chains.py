@@ -69,6 +69,29 @@ def test_gpu_pool_many_chains_lockstep_and_files(tmp_path):
         assert np.array_equal(small.chain(0)[k], pool.chain(0)[k], equal_nan=True)
 
 
+def test_gpu_pool_result_files_match_the_reference_files(tmp_path):
+    """SURVEY 8(f4) on the tier the driver runs: ChainPool.save() after a GPU-evaluated run against
+    the ten files the reference's own chain writes (tests/golden/chain_files_golden.npz: weighting by
+    residence time, thinning to maxmodels, the reference's dtypes).  Models, noise and vp/vs files
+    exactly; likelihoods and misfits to one float32 ulp (device forward values differ in the last bits)."""
+    want = np.load(os.path.join(GOLDEN, 'chain_files_golden.npz'))
+    case = dict(CASES['tutorial'])
+    case['initparams'] = dict(case['initparams'], maxmodels=int(want['maxmodels']))
+    pool = make_pool(None, DATA, case, seeds=[int(want['seed'])], evaluator=gpu_evaluator).run()
+    assert pool.save(str(tmp_path)) == 10
+    names = sorted(k for k in want.files if k.startswith('c000_'))
+    assert sorted(f[:-4] for f in os.listdir(str(tmp_path / 'data')) if f.endswith('.npy')) == names
+    for k in names:
+        a, b = want[k], np.load(str(tmp_path / 'data' / (k + '.npy')))
+        assert a.dtype == b.dtype and a.shape == b.shape, k
+        if k.endswith('likes') or k.endswith('misfits'):
+            assert np.allclose(a, b, rtol=3e-7, atol=0), k
+            assert np.mean(a == b) > 0.99, k
+        else:
+            assert np.array_equal(a, b, equal_nan=True), k
+    assert os.path.exists(str(tmp_path / 'data' / 'test_config.pkl'))
+
+
 def _shard_worker(rank, world, port, q):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -159,3 +182,44 @@ maxmodels = 50000
     assert list(pool.seeds) == [np.random.RandomState(11).randint(1000)] + list(pool.seeds[1:])
     for i in range(6):
         assert np.array_equal(pool.chain(i)['models'], ref.chain(i)['models'], equal_nan=True)
+
+
+def test_rccl_branches_execute_on_one_gpu(tmp_path):
+    """The "nccl" (= RCCL) code paths of the package on this box's single GPU: a one-rank process
+    group in a child process runs the device-side collectives of bench.py's timing protocol (barrier
+    with device_ids, MAX all-reduce on the device) and of the gathers (all_gather, gather-to-root,
+    ragged gather, ChainPool.gather / gather_final with device tensors)."""
+    import subprocess
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], HSA_ENABLE_IPC_MODE_LEGACY='0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from bayhunter_amd.distributed import gather_ragged_to_root, gather_rows, gather_rows_to_root, max_over_ranks
+dist.barrier(device_ids=[0])
+assert max_over_ranks(2.5, device='cuda') == 2.5
+x = torch.arange(12, dtype=torch.float32, device='cuda').reshape(4, 3)
+assert torch.equal(gather_rows(x, 4), x) and torch.equal(gather_rows_to_root(x, 4), x)
+assert torch.equal(gather_ragged_to_root(x)[0], x)
+from chain_scenario import CASES, joint_target
+from bayhunter_amd.chains import ChainPool, GpuEvaluator
+case = CASES['fixednoise']
+joint = joint_target(%r)
+ip = dict(case['initparams'], iter_burnin=40, iter_main=30, acceptance=(40, 100), maxmodels=11)
+pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=[5, 6, 7], shard=(0, 1), evaluator=GpuEvaluator(joint)).run()
+full = pool.gather()
+assert np.array_equal(full['likes'], pool.likes, equal_nan=True) and full['models'].shape[0] == 3
+fin = pool.gather_final()
+assert len(fin) == 3 and all(np.array_equal(a, pool.final(i), equal_nan=True) for i, a in enumerate(fin))
+dist.barrier(device_ids=[0])
+dist.destroy_process_group()
+print('rccl ok')
+""" % (ROOT, os.path.join(ROOT, 'tests', 'scenarios'), DATA)
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, '-c', code, str(port)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
