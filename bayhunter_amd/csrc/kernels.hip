@@ -557,12 +557,12 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         if (ZR) {
             cd zr_r, zr_z;
             cd crf = rf_phase3_task(Sm, lo, P, nl, j, &zr_r, &zr_z);
-            st_cd(Sm + 2 * j, crf);
+            rf_xst(Sm, j, crf);
             st_cd(Sm + lo.per_model + 2 * j, zr_r);
             st_cd(Sm + lo.per_model + 2 * P.nfreq + 2 * j, zr_z);
         } else {
             cd crf = rf_phase3_task(Sm, lo, P, nl, j);
-            st_cd(Sm + 2 * j, crf);
+            rf_xst(Sm, j, crf);
         }
     }
     // frequencies whose filter weight is below 1e-24 (rf_host.h): zero
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     for (int idx = tid; idx < Mb * nzero; idx += RF_T) {
         int m = idx / nzero, j = P.nact + (idx - m * nzero);
         double *Sm = S + (long)m * pm;
-        st_cd(Sm + 2 * j, mk(0., 0.));
+        rf_xst(Sm, j, mk(0., 0.));
         if (ZR) {
             st_cd(Sm + lo.per_model + 2 * j, mk(0., 0.));
             st_cd(Sm + lo.per_model + 2 * P.nfreq + 2 * j, mk(0., 0.));
@@ -587,22 +587,22 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     rf_block_fft(S, pm, Mb, n, P, A.tw, tid);
     for (int idx = tid; idx < Mb * P.nout; idx += RF_T) {
         int m = idx / P.nout, i = idx - m * P.nout;
-        A.out[(long)(b0 + m) * P.out_stride + P.out_off + i] = P.qn * S[(long)m * pm + 2 * i];
+        A.out[(long)(b0 + m) * P.out_stride + P.out_off + i] = P.qn * S[(long)m * pm + 2 * rf_swz(i)];
     }
     if (ZR) {   // iftr2 (greens.cpp:161-194): one FFT of cx = radial + i*vertical
         __syncthreads();
         for (int idx = tid; idx < Mb * n; idx += RF_T) {
             int m = idx / n, i = idx - m * n;
             double *Sm = S + (long)m * pm;
-            st_cd(Sm + 2 * i, rf_fft_pair_entry(Sm + lo.per_model, Sm + lo.per_model + 2 * P.nfreq, n, i));
+            rf_xst(Sm, i, rf_fft_pair_entry(Sm + lo.per_model, Sm + lo.per_model + 2 * P.nfreq, n, i));
         }
         __syncthreads();
         rf_block_fft(S, pm, Mb, n, P, A.tw, tid);
         for (int idx = tid; idx < Mb * n; idx += RF_T) {
             int m = idx / n, i = idx - m * n;
             const double *Sm = S + (long)m * pm;
-            A.out_fr[(long)(b0 + m) * n + i] = P.qn * Sm[2 * i];
-            A.out_fz[(long)(b0 + m) * n + i] = P.qn * Sm[2 * i + 1];
+            A.out_fr[(long)(b0 + m) * n + i] = P.qn * Sm[2 * rf_swz(i)];
+            A.out_fz[(long)(b0 + m) * n + i] = P.qn * Sm[2 * rf_swz(i) + 1];
         }
     }
 }

@@ -52,6 +52,9 @@ struct RfLaunch {
 
 // LDS block of one model, in doubles.  The FFT buffer [0, 2*nsamp) overlays the spectrum and -- once
 // P3 is over -- the parameter/coefficient region.
+// doubles between the coefficient blocks of consecutive interfaces: 32 used + 2, so that the lanes of
+// phase 2 (one per interface) do not all store into the same banks (32 doubles = one bank row)
+enum { RF_COEF = 34 };
 struct RfLayout {
     int L, off_par, off_coef, off_sc, per_model;
 };
@@ -62,8 +65,8 @@ BH_HD RfLayout rf_layout(int Lmax, int nsamp)
     lo.L = Lmax;
     lo.off_par = 2 * nfreq;            // [9][L]: d, vp, vs, rho, 1/(pi qp), 1/(pi qs), 1/vp^2, 1/vs^2,
                                        //         interface coefficients real?
-    lo.off_coef = lo.off_par + 9 * Lmax; // [L][32]: rd, td, ru, tu of interface i (above layer i)
-    lo.off_sc = lo.off_coef + 32 * Lmax; // 16 scalars
+    lo.off_coef = lo.off_par + 9 * Lmax; // [L][RF_COEF]: rd, td, ru, tu of interface i (above layer i)
+    lo.off_sc = lo.off_coef + RF_COEF * Lmax; // 16 scalars
     int need = lo.off_sc + 16;
     lo.per_model = need > 2 * nsamp ? need : 2 * nsamp;
     // A wave of phase 3 that straddles two models reads the same offsets of both blocks.  With a block
@@ -239,7 +242,7 @@ BH_DEV void rf_phase2_interface(double *S, const RfLayout &lo, const RfLaunch &P
                                 double vp0_in, double vs0_in)
 {
     const double *par = S + lo.off_par;
-    double *coef = S + lo.off_coef + 32 * i;
+    double *coef = S + lo.off_coef + RF_COEF * i;
     cm2 rd = cm2_zero(), td = cm2_zero(), ru = cm2_zero(), tu = cm2_zero();
     double u = P.slowness;
     if (i == 0) {
@@ -322,7 +325,7 @@ BH_DEV cd rf_phase3_body(const double *S, const RfLayout &lo, const RfLaunch &P,
         cd plc = csqrt_fast(gp * par[6 * lo.L + i] - P.p2);         // Q finite -> im != 0
         cd slc = csqrt_fast(gs * par[7 * lo.L + i] - P.p2);
         cd e11 = cexp_(miwd * plc), e22 = cexp_(miwd * slc);
-        const double *ci = coef + 32 * i, *cn = coef + 32 * (i + 1);
+        const double *ci = coef + RF_COEF * i, *cn = coef + RF_COEF * (i + 1);
         cm2 nt;
         if (i == 0) nt = to_cm2(ld_m2(ci + 16, (const M *)nullptr));                   // nt = ru[1]
         else nt = ld_m2(ci + 16, (const M *)nullptr) + (ld_m2(ci + 8, (const M *)nullptr) * nb) * q;     // ru + td*nb*q
@@ -387,6 +390,16 @@ BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P,
 #endif
 
 // ---- P4: inverse FFT pieces (greens.cpp:136-158, fork.cpp:10-60) ---------------------------------------
+// Where complex element e of the FFT buffer lives.  The bit-reversal permutation makes the 64 lanes
+// of a wave touch elements 8 apart (128 bytes): all in the same few LDS banks, a 32-way conflict
+// (measured: a third of the kernel's bank-conflict cycles for 5 % of its LDS instructions).  XOR-ing
+// bits 4..7 of the index into bits 0..3 permutes elements only inside their 16-element (256-byte)
+// row, so unit-stride runs (butterflies, spectrum, output) stay conflict-free, while elements 8
+// apart now spread over a row: 2-way.
+BH_HD int rf_swz(int e) { return e ^ ((e >> 4) & 15); }
+BH_DEV cd rf_xld(const double *X, int e) { return ld_cd(X + 2 * rf_swz(e)); }
+BH_DEV void rf_xst(double *X, int e, cd v) { st_cd(X + 2 * rf_swz(e), v); }
+
 BH_DEV unsigned rf_bitrev(unsigned i, int log2n)
 {
     unsigned r = 0;
@@ -396,17 +409,16 @@ BH_DEV unsigned rf_bitrev(unsigned i, int log2n)
 // Hermitian extension: cx[i] = conj(cx[n-i]) for i in (n/2, n)
 BH_DEV void rf_fft_hermitian(double *X, int n, int i)
 {
-    cd v = ld_cd(X + 2 * (n - i));
-    st_cd(X + 2 * i, conj(v));
+    rf_xst(X, i, conj(rf_xld(X, n - i)));
 }
 // bit-reversal permutation fused with the 1/sqrt(n) scaling of fork.cpp:30-45: handle pair (i, rev i)
 BH_DEV void rf_fft_bitrev_scale(double *X, int n, int log2n, double sc, int i)
 {
     int j = (int)rf_bitrev((unsigned)i, log2n);
     if (i > j) return;
-    cd xi = ld_cd(X + 2 * i), xj = ld_cd(X + 2 * j);
-    st_cd(X + 2 * j, xi * sc);
-    st_cd(X + 2 * i, xj * sc);
+    cd xi = rf_xld(X, i), xj = rf_xld(X, j);
+    rf_xst(X, j, xi * sc);
+    rf_xst(X, i, xj * sc);
     (void)n;
 }
 // iftr2 (greens.cpp:161-194): entry i of cx = cx1 + i*cx2 built from the two half spectra
@@ -421,10 +433,10 @@ BH_DEV void rf_fft_butterfly(double *X, const double *tw, int l, int bf)
 {
     int m = bf & (l - 1), i = ((bf - m) << 1) + m;
     cd w = ld_cd(tw + 2 * (l + m));
-    cd a = ld_cd(X + 2 * i), b = ld_cd(X + 2 * (i + l));
+    cd a = rf_xld(X, i), b = rf_xld(X, i + l);
     cd tmp = w * b;
-    st_cd(X + 2 * (i + l), a - tmp);
-    st_cd(X + 2 * i, a + tmp);
+    rf_xst(X, i + l, a - tmp);
+    rf_xst(X, i, a + tmp);
 }
 
 

@@ -196,12 +196,12 @@ static int rf_hostsim_model(int nlay, const double *h, const double *vp, const d
     std::vector<cd> spec(P.nfreq);
     for (int j = 0; j < P.nfreq; j++) spec[j] = j < P.nact ? rf_phase3_task(S.data(), lo, P, nlay, j) : mk(0., 0.);
     double *X = S.data();
-    for (int j = 0; j < P.nfreq; j++) st_cd(X + 2 * j, spec[j]);
+    for (int j = 0; j < P.nfreq; j++) rf_xst(X, j, spec[j]);
     for (int i = nsamp / 2 + 1; i < nsamp; i++) rf_fft_hermitian(X, nsamp, i);
     for (int i = 0; i < nsamp; i++) rf_fft_bitrev_scale(X, nsamp, P.log2n, P.sc, i);
     for (int l = 1; l < nsamp; l <<= 1)
         for (int bf = 0; bf < nsamp / 2; bf++) rf_fft_butterfly(X, tw.data(), l, bf);
-    for (int i = 0; i < nout; i++) rf[i] = P.qn * X[2 * i];
+    for (int i = 0; i < nout; i++) rf[i] = P.qn * X[2 * rf_swz(i)];
     return 0;
 }
 }  // namespace bh
