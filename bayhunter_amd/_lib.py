@@ -54,13 +54,33 @@ class BayHunterAmdError(RuntimeError):
     pass
 
 
+def source_hash():
+    """Hash of everything the library is built from (sources, headers, the C ABI header, the
+    compiler flags): compiled into the library (bh_version) and stamped on profiles, so that a
+    number can be tied to the code that produced it."""
+    import hashlib
+    h = hashlib.sha256()
+    extra = os.environ.get("BH_EXTRA_HIPCC_FLAGS", "")
+    h.update((" ".join(HIPCC_FLAGS) + "|" + extra).encode())
+    for f in [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(_HERE, "..", "include", "bayhunter_amd.h")]:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
+    """Source hash recorded when libbayhunter_amd.so was last built here ('' if unknown)."""
+    try:
+        with open(LIB_PATH + ".srchash") as fh:
+            return fh.read().strip()
+    except (IOError, OSError):
+        return ""
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps.append(os.path.join(_HERE, "..", "include", "bayhunter_amd.h"))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    """By content, not by time stamp: a library pushed from another tree is rebuilt when its
+    recorded source hash is not this tree's."""
+    return not os.path.exists(LIB_PATH) or built_hash() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -69,11 +89,20 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("BH_EXTRA_HIPCC_FLAGS", "").split()      # compiler experiments
-    cmd = [hipcc] + HIPCC_FLAGS + extra + SOURCES + ["-o", LIB_PATH]
+    sh = source_hash()
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ['-DBH_SRC_HASH="%s"' % sh] + SOURCES + ["-o", LIB_PATH]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, cwd=CSRC, check=True)
+    with open(LIB_PATH + ".srchash", "w") as fh:
+        fh.write(sh + "\n")
     return LIB_PATH
+
+
+def loaded_hash():
+    """The source hash compiled into the loaded library (bh_version: '... src <hash>')."""
+    v = load().bh_version().decode()
+    return v.rsplit("src ", 1)[1] if "src " in v else ""
 
 
 class ChainConfig(C.Structure):

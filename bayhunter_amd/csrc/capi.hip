@@ -189,7 +189,10 @@ int pick_rf_M(int B, int Lmax, int nsamp)
 
 extern "C" {
 
-const char *bh_version(void) { return "bayhunter_amd 0.1 (gfx950)"; }
+#ifndef BH_SRC_HASH
+#define BH_SRC_HASH "unknown"
+#endif
+const char *bh_version(void) { return "bayhunter_amd 0.2 (gfx950) src " BH_SRC_HASH; }
 const char *bh_last_error(void) { return g_err.c_str(); }
 
 int bh_device_count(int *count)

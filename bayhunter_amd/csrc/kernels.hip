@@ -48,6 +48,15 @@ struct LdsLay {
     __device__ __forceinline__ void set_rho(int i, float v) { base[(3 * L + i) * SWD_T] = v; }
 };
 
+// nlay outside 1..Lmax (a stale depth hint, an nlay array changed behind the engine's back): the
+// search is not run on a truncated model; the row is NaN and the flag BH_MODEL_BAD_DEPTH.
+__device__ __forceinline__ void swd_bad_depth(const SwdArgs &A, const SwdTargetDev &tg, int t, long b)
+{
+    double *out = A.out + b * A.out_stride + tg.out_off;
+    for (int k = 0; k < tg.nper; k++) out[k] = __builtin_nan("");
+    A.err[b * A.ntargets + t] = 2;
+}
+
 // Per-target work queue: lanes pull model indices from an atomic counter (zeroed by the launcher).
 // A lane that pulls a task copies that model's fp64 row (contiguous, 32*L bytes) into ITS column of
 // the layer-major LDS image, rounding to fp32 like f2py does (surf96_modsw.py:68-82).  At kernel
@@ -61,13 +70,18 @@ struct QueueSrc {
     long cur;
     __device__ __forceinline__ int next(LdsLay &lay, double *&out, double *&cws, double *&cbws)
     {
-        unsigned int b = atomicAdd(counter, 1u);
-        if (b >= (unsigned int)A.B) return 0;
-        if (A.order) b = (unsigned int)A.order[b];
-        cur = b;
+        unsigned int b;
+        int nl;
         const int L = A.Lmax;
-        int nl = A.nlay[b];
-        nl = nl < 1 ? 1 : (nl > L ? L : nl);
+        for (;;) {
+            b = atomicAdd(counter, 1u);
+            if (b >= (unsigned int)A.B) return 0;
+            if (A.order) b = (unsigned int)A.order[b];
+            nl = A.nlay[b];
+            if (nl >= 1 && nl <= L) break;
+            swd_bad_depth(A, tg, t, b);       // not a model of this batch's depth: flagged, never truncated
+        }
+        cur = b;
         const long g = (long)b * A.mstride;
         if (A.vec2) {   // rows 16-byte aligned: two layers per load (half the memory requests)
             for (int l = 0; l < nl; l += 2) {
@@ -136,20 +150,24 @@ struct TeamSrc {
                              // from the per-target counter until it runs past the batch
     __device__ __forceinline__ int next(TeamLay &lay, double *&out, double *&cws, double *&cbws)
     {
-        if (queue) {
-            int nb = 0;
-            if (lane == 0) nb = (int)atomicAdd(queue, 1u);
-            nb = __shfl(nb, (int)(threadIdx.x & 63) - lane, 64);      // the team's lane 0
-            if (nb >= A.B) return 0;
-            b = A.order ? A.order[nb] : nb;
-        } else {
-            if (taken) return 0;
-            taken = 1;
-            if (A.order) b = A.order[b];
-        }
         const int L = A.Lmax;
-        int nl = A.nlay[b];
-        nl = nl < 1 ? 1 : (nl > L ? L : nl);
+        int nl;
+        for (;;) {
+            if (queue) {
+                int nb = 0;
+                if (lane == 0) nb = (int)atomicAdd(queue, 1u);
+                nb = __shfl(nb, (int)(threadIdx.x & 63) - lane, 64);      // the team's lane 0
+                if (nb >= A.B) return 0;
+                b = A.order ? A.order[nb] : nb;
+            } else {
+                if (taken) return 0;
+                taken = 1;
+                if (A.order) b = A.order[b];
+            }
+            nl = A.nlay[b];
+            if (nl >= 1 && nl <= L) break;
+            if (lane == 0) swd_bad_depth(A, tg, t, b);
+        }
         const long g = b * A.mstride;
         for (int l = lane; l < nl; l += nlanes) {
             lay.set_d(l, (float)A.h[g + l]);
@@ -587,7 +605,10 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     rf_block_fft(S, pm, Mb, n, P, A.tw, tid);
     for (int idx = tid; idx < Mb * P.nout; idx += RF_T) {
         int m = idx / P.nout, i = idx - m * P.nout;
-        A.out[(long)(b0 + m) * P.out_stride + P.out_off + i] = P.qn * S[(long)m * pm + 2 * rf_swz(i)];
+        const int nl = A.nlay[b0 + m];
+        const bool bad_depth = nl < 1 || nl > L;       // (the phases ran on a clamped copy: discard)
+        A.out[(long)(b0 + m) * P.out_stride + P.out_off + i] =
+            bad_depth ? __builtin_nan("") : P.qn * S[(long)m * pm + 2 * rf_swz(i)];
     }
     if (ZR) {   // iftr2 (greens.cpp:161-194): one FFT of cx = radial + i*vertical
         __syncthreads();

@@ -82,8 +82,11 @@ int  bh_set_device(int device);
  * pulls a model from the work queue).  Values are rounded to fp32 on load exactly like f2py does
  * for the reference (surf96_modsw.py:68-82).  `targets` is a HOST array.
  * out[b*out_stride + out_off + k], k < nper: phase/group velocity; failed and later periods are 0.
- * err[b*ntargets + t]: the reference's err flag for that (model, target).
+ * err[b*ntargets + t]: the reference's err flag for that (model, target) -- 0, or 1 when no root of
+ * the fundamental mode was found -- or BH_MODEL_BAD_DEPTH (2) when nlay[b] is outside 1..Lmax: such a
+ * model is not evaluated on a truncated layer stack; its dispersion row (and receiver function) is NaN.
  * workspace: only needed when some target has mode > 1 (bh_swd_workspace_bytes). */
+#define BH_MODEL_BAD_DEPTH 2
 size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets);
 /* Several kernels compute the same values, bit for bit:
  *   BH_SWD_LANE     one search per lane (persistent lanes, work queue): the throughput form,
@@ -115,7 +118,9 @@ int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const doubl
  * the i-th search slot works on; results still land in row order[i].  The lanes of a wave run in
  * lock step, so putting models of similar depth and similar search length next to each other
  * saves 10 % at half a million models (bayhunter_amd/engine.py orders by layer count, then by the
- * S-wave travel time through the stack).  order == NULL is bh_swd_batch. */
+ * S-wave travel time through the stack).  order == NULL is bh_swd_batch.  `order` is trusted: it
+ * must be a permutation of 0..B-1 (a repeated index evaluates that model twice and leaves another
+ * row unwritten; an index outside the batch reads and writes outside the caller's buffers). */
 int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                          const double *vp, const double *vs, const double *rho, int ntargets,
                          const bh_swd_target *targets, const double *periods, double *out,

@@ -597,3 +597,33 @@ np.savez(sys.argv[1], bad=bad, **{'o%%d' %% i: ref[i][0] for i in range(6)}, **{
             assert np.array_equal(got['e%d' % i][:, 0], werr), (kernel, i)
             ok = werr == 0
             assert np.abs(got['o%d' % i][ok] - want[ok]).max() <= TOL_PHASE, (kernel, i)
+
+
+def test_model_deeper_than_the_launch_is_flagged_not_truncated(lib, oracle):
+    """nlay outside 1..Lmax (here: a depth hint that understates three models, and a zero): the row
+    is NaN and the flag 2 (BH_MODEL_BAD_DEPTH) in every kernel form, the likelihood of such a model is
+    the failure value, and the other models of the batch are untouched."""
+    import torch
+    from bayhunter_amd import _lib
+    from bayhunter_amd.engine import DeviceModels, ForwardEngine, RfSpec, SwdSpec
+    per = np.linspace(1, 41, 21)
+    H, VP, VS, RHO, nl = draw_models(300, (2, 6), seed=61, Lmax=8)
+    bad = np.array([7, 130, 299])
+    nl2 = nl.copy()
+    nl2[bad[:2]] = 8                                     # deeper than the hint below
+    nl2[bad[2]] = 0
+    eng = ForwardEngine(swd=[SwdSpec('rdispph', per), SwdSpec('ldispgr', per)], rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
+    m = eng.upload(H, VP, VS, RHO, nl2)
+    hinted = DeviceModels(m.packed, m.nlay, depth=6)     # kernels size their LDS for 6 layers
+    want, werr, _ = oracle.swd_batch(H, VP, VS, RHO, nl, per, 2, 0)
+    good = np.setdiff1d(np.arange(300), bad)
+    for mode in ('lane', 'team', 'team256', 'team16', 'team8'):
+        _lib.set_swd_kernel(mode)
+        try:
+            out, err = eng.run(hinted)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_swd_kernel('auto')
+        out, err = out.cpu().numpy(), err.cpu().numpy()
+        assert np.all(err[bad] == 2) and np.all(np.isnan(out[bad])), mode
+        assert np.array_equal(err[good, 0], werr[good]) and np.array_equal(out[good, :21][werr[good] == 0], want[good][werr[good] == 0]), mode

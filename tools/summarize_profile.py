@@ -53,7 +53,19 @@ def main(tag, src=None):
                 'read_bytes': 2.0 * d['FETCH_SIZE'] * 1024, 'write_bytes': d['WRITE_SIZE'] * 1024,
                 'hbm_bytes': 2.0 * d['FETCH_SIZE'] * 1024 + d['WRITE_SIZE'] * 1024,
                 'avg_ms_rocprof': dur.get(k)}
-    json.dump({'tag': tag, 'config': cfg, 'kernels': traffic},
+    # stamp: the code the counters belong to (bench.py drops them when its own library or its live
+    # kernel time disagree)
+    import subprocess
+    hf = os.path.join(src, 'src_hash.txt')
+    src_hash = open(hf).read().strip() if os.path.exists(hf) else ''
+    try:
+        sha = subprocess.run(['git', '-C', root, 'rev-parse', 'HEAD'], capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(['git', '-C', root, 'status', '--porcelain', '--', 'bayhunter_amd', 'include'],
+                                    capture_output=True, text=True).stdout.strip())
+    except OSError:
+        sha, dirty = '', False
+    json.dump({'tag': tag, 'config': cfg, 'lib_src_hash': src_hash, 'git_sha': sha + ('+dirty' if dirty else ''),
+               'kernels': traffic},
               open(os.path.join(dst, tag + '_traffic.json'), 'w'), indent=1)
     with open(os.path.join(dst, tag + '_rocprofv3_summary.md'), 'w') as out:
         out.write('# %s rocprofv3 summary (MI355X)\n\nbench config: `%s`\n\n' % (tag, cfg))
