@@ -437,15 +437,21 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     swd_state_init(S);
     BH_TP_DECL;
     long rounds = 0;
+    int nlm_seen = -1, cap = 1, ja = 0, ra = 0;
     for (;;) {
         swd_driver(S, lay, src, tg, perl, A.B, true);
         if (S.st == SWD_ST_DONE) break;
         BH_TP(0);
         const int nlm = S.mmax - S.llw;
-        int cap = nlm > 0 ? NL / nlm : SWD_TEAMW_NT;
-        if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;                // one quad per Rayleigh trial
-        if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
-        if (cap < 1) cap = 1;
+        if (nlm != nlm_seen) {            // a new model: slots per round, and which (trial, layer) this lane assembles
+            nlm_seen = nlm;
+            cap = nlm > 0 ? NL / nlm : SWD_TEAMW_NT;
+            if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;            // one quad per Rayleigh trial
+            if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
+            if (cap < 1) cap = 1;
+            ja = (cap > 1 && nlm > 0) ? lane / nlm : 0;
+            ra = lane - ja * nlm;
+        }
         const TeamwRound R = swd_teamw_round(S, tg, perl, cap);
         const int nt = R.nt;
         double mc, mom;                                                 // slot wl of the plan
@@ -453,7 +459,6 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         if (lane < nt) { tcl[lane] = mc; toml[lane] = mom; }
         __syncthreads();
         BH_TP(1);
-        const int ja = (cap > 1 && nlm > 0) ? lane / nlm : 0, ra = lane - ja * nlm;
         const int jq = 16 * wave + (wl >> 2);
         if (cap > 1) {
             if (ja < nt && nlm > 0) {

@@ -153,18 +153,20 @@ BH_DEV void swd_ray_layer_matrix(const Lay &lay, int i0, double wvno, double wvn
     swd_dnka(a, wvno2, gam, gammk, rho1, v);
 }
 
-// E vector of the bottom half-space, surfdisp96.f:785-808 (omega already clamped)
+// E vector of the bottom half-space, surfdisp96.f:785-808 (omega already clamped).  (Lean quotient /
+// root sequences: bit-identical for these normal-range operands, bh_selftest_division.)
 template <class Lay>
 BH_DEV void swd_ray_halfspace(const Lay &lay, int mmax, double wvno, double wvno2, double omega,
                               double e[5])
 {
-    double xka = omega / (double)lay.a(mmax - 1);
-    double xkb = omega / (double)lay.b(mmax - 1);
+    const double am = (double)lay.a(mmax - 1), bm = (double)lay.b(mmax - 1);
+    double xka = xdiv(omega, am);
+    double xkb = xdiv(omega, bm);
     double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
-    double ra = sqrt(wvnop * wvnom);
+    double ra = xsqrt(wvnop * wvnom);
     wvnop = wvno + xkb; wvnom = fabs(wvno - xkb);
-    double rb = sqrt(wvnop * wvnom);
-    double t = (double)lay.b(mmax - 1) / omega;
+    double rb = xsqrt(wvnop * wvnom);
+    double t = xdiv(bm, omega);
     double gammk = 2.0 * t * t, gam = gammk * wvno2, gamm1 = gam - 1.0;
     double rho1 = (double)lay.rho(mmax - 1);
     e[0] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
