@@ -17,6 +17,8 @@ struct SwdArgs {
     int B, Lmax, ntargets, out_stride;
     int mstride;             // elements between consecutive models in h/vp/vs/rho
     int vec2;                // rows are 16-byte aligned and Lmax is even: fetch two layers per load
+    int stage;               // swd_kernel: > 0: a search's results wait in LDS (that many periods per lane)
+                             // and are written as one row
     const int *nlay;
     const int *order;        // optional: the i-th search taken from the queue is model order[i]
     const double *h, *vp, *vs, *rho;

@@ -11,6 +11,7 @@
 // and not MFMA-shaped ("Roofline").  HBM traffic is the algorithmic minimum: each model
 // byte is read once, each output written once; everything else lives in LDS/registers.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 #include "rf_core.h"
 #include "swd_core.h"
@@ -74,6 +75,9 @@ struct QueueSrc {
         int nl;
         const int L = A.Lmax;
         for (;;) {
+            // (Handing the queue out in chunks of 64 consecutive slots per wave, so that a wave holds
+            // neighbours of the processing order, was measured: 5.7 % slower -- slots reserved by a
+            // wave whose lanes are still busy wait while other waves idle at the end.  DESIGN section 4.1.)
             b = atomicAdd(counter, 1u);
             if (b >= (unsigned int)A.B) return 0;
             if (A.order) b = (unsigned int)A.order[b];
@@ -109,7 +113,33 @@ struct QueueSrc {
         }
         return nl;
     }
-    __device__ __forceinline__ void done(int err) { A.err[cur * A.ntargets + t] = err; }
+    // Results are real*4 values (surfdisp96.f:298-310).  With room in LDS a search's values wait in
+    // this lane's column of a [period][lane] fp32 image and the row is written when the search is
+    // over: back-to-back 16-byte stores of one 8*nper-byte run, instead of one scattered store every
+    // other period -- which the memory side tallies at 32-64 bytes each (2.7x the row, round 1).
+    float *stage;                 // lds + lane, or nullptr: store as the periods converge
+    __device__ __forceinline__ void put(SwdState &S, int k, int kmax, float v)
+    {
+        if (stage) stage[(k - 1) * SWD_T] = v;
+        else swd_put_direct(S, k, kmax, v);
+    }
+    __device__ __forceinline__ void fill_zero(SwdState &S, int k, int kmax)
+    {
+        if (stage) { for (int i = k; i <= kmax; i++) stage[(i - 1) * SWD_T] = 0.f; }
+        else swd_zero_direct(S, k, kmax);
+    }
+    __device__ __forceinline__ void done(int err)
+    {
+        A.err[cur * A.ntargets + t] = err;
+        if (stage) {
+            const int n = tg.nper;
+            double *o = A.out + cur * A.out_stride + tg.out_off;
+            int k = 0;
+            if (((unsigned long long)o & 15) && n > 0) { o[0] = (double)stage[0]; k = 1; }   // to a 16-byte boundary
+            for (; k + 1 < n; k += 2) swd_store_pair(o + k, stage[k * SWD_T], stage[(k + 1) * SWD_T]);
+            if (k < n) o[k] = (double)stage[k * SWD_T];
+        }
+    }
     __device__ __forceinline__ void sphere(LdsLay &lay, int mmax, int ifunc) { swd_sphere(lay, mmax, ifunc); }
 };
 
@@ -120,7 +150,7 @@ __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int t = blockIdx.y;
     const SwdTargetDev tg = A.tg[t];
     LdsLay lay{lds + threadIdx.x, A.Lmax};
-    QueueSrc src{A, tg, A.counters + t, t, 0};
+    QueueSrc src{A, tg, A.counters + t, t, 0, A.stage ? lds + 4 * A.Lmax * SWD_T + threadIdx.x : nullptr};
     swd_lane(lay, src, tg, A.periods + tg.per_off, A.B, nullptr);
 }
 
@@ -186,6 +216,16 @@ struct TeamSrc {
     __device__ __forceinline__ void done(int err)
     {
         if (lane == 0) A.err[b * A.ntargets + t] = err;
+    }
+    // every lane of the team runs the driver: one of them stores
+    __device__ __forceinline__ void put(SwdState &S, int k, int kmax, float v)
+    {
+        if (lane == 0) swd_put_direct(S, k, kmax, v);
+        else if ((k & 1) && k != kmax) S.pend = v;      // (keep the state identical on all lanes)
+    }
+    __device__ __forceinline__ void fill_zero(SwdState &S, int k, int kmax)
+    {
+        if (lane == 0) swd_zero_direct(S, k, kmax);
     }
     // The team shares one copy of the model: the lanes of a wave transform it in lock step (every
     // lane reads a value before any lane writes it), a second wave must not transform it again.
@@ -691,7 +731,16 @@ hipError_t launch_swd_team(const SwdArgs &A, int team, int resident_waves, hipSt
 
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
 {
+    // model image [4][Lmax][64] fp32, + the result image [max nper][64] fp32 when eight waves per CU
+    // (the register-limited residency) still fit 160 KiB with it
     size_t lds = (size_t)4 * A.Lmax * SWD_T * sizeof(float);
+    int maxper = 0;
+    for (int t = 0; t < A.ntargets; t++) maxper = A.tg[t].nper > maxper ? A.tg[t].nper : maxper;
+    const size_t staged = lds + (size_t)maxper * SWD_T * sizeof(float);
+    SwdArgs B = A;
+    static const bool no_stage = std::getenv("BH_SWD_NO_STAGE") != nullptr;      // A/B switch (diagnostic)
+    B.stage = (!no_stage && maxper > 0 && 8 * staged <= 160 * 1024) ? maxper : 0;   // periods staged per lane
+    if (B.stage) lds = staged;
     static size_t lds_set[16] = {0};
     hipError_t e0 = ensure_dyn_lds((const void *)swd_kernel, lds, lds_set);
     if (e0 != hipSuccess) return e0;
@@ -707,7 +756,7 @@ hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
     if (gx > 3 * per_target) gx = per_target;
     hipError_t e = hipMemsetAsync(A.counters, 0, BH_NT * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(swd_kernel, dim3(gx, A.ntargets), dim3(SWD_T), lds, stream, A);
+    hipLaunchKernelGGL(swd_kernel, dim3(gx, A.ntargets), dim3(SWD_T), lds, stream, B);
     return hipGetLastError();
 }
 

@@ -364,6 +364,9 @@ BH_DEV void swd_put(double *out, int k, int kmax, float v, float &pend)      // 
 }
 
 // ---- the search ----------------------------------------------------------------------------------
+struct SwdState;
+BH_DEV void swd_put_direct(SwdState &S, int k, int kmax, float v);
+BH_DEV void swd_zero_direct(SwdState &S, int k, int kmax);
 struct SwdTargetDev {
     int iwave, igr, mode, iflsph, nper, per_off, out_off, _pad;
 };
@@ -482,6 +485,13 @@ BH_DEV bool swd_neville(NevMem &n, int &m, bool nev2, double c1, double del1, do
     return true;
 }
 
+BH_DEV void swd_put_direct(SwdState &S, int k, int kmax, float v) { swd_put(S.out, k, kmax, v, S.pend); }
+BH_DEV void swd_zero_direct(SwdState &S, int k, int kmax)
+{
+    if (!(k & 1)) S.out[k - 2] = (double)S.pend;      // an odd period's value was still waiting
+    for (int i = k; i <= kmax; i++) S.out[i - 1] = 0.0;
+}
+
 BH_DEV void swd_state_init(SwdState &S)
 {
     S.mmax = 1; S.llw = 1; S.err = 0; S.betmx = 0.f; S.cc = 0; S.cfail = 0;
@@ -512,7 +522,11 @@ BH_DEV double swd_bracket_next(double &c1, int &idir, double clow, double dc)
 //            the next model of this lane's target into `lay` and returns its layer count (>= 1), or
 //            0 when the queue is drained; `void done(int err)` reports the reference's err flag of
 //            the task just finished; `void sphere(Lay &, int mmax, int ifunc)` applies swd_sphere to
-//            the model just loaded, exactly once (a team shares one copy of the model).
+//            the model just loaded, exactly once (a team shares one copy of the model);
+//            `void put(SwdState &, int k, int kmax, float v)` takes the value of period k (1-based),
+//            `void fill_zero(SwdState &, int k, int kmax)` zeroes periods k..kmax (swd_put_direct /
+//            swd_zero_direct below store straight to S.out; the throughput kernel stages a search's
+//            values in LDS and writes the row once).
 //   cws/cbws per-task c(k)/cb(k) arrays for mode > 1 (stride `wss` doubles), unused for mode 1
 //   allow_fetch  false: return (with S.ev == SWD_EV_FETCH pending) instead of loading the next task --
 //            used where the driver runs in the middle of a round (swd_team.h, wide teams)
@@ -610,10 +624,10 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
             }
             float cc0 = (float)S.ck, cc1b = (float)S.c1;
             if (igr == 0) {
-                swd_put(S.out, S.k, kmax, cc0, S.pend);
+                src.put(S, S.k, kmax, cc0);
             } else {
                 float gvel = (1 / S.t1a - 1 / S.t1b) / (1 / (S.t1a * cc0) - 1 / (S.t1b * cc1b));
-                swd_put(S.out, S.k, kmax, gvel, S.pend);
+                src.put(S, S.k, kmax, gvel);
             }
             S.cprev = S.ck;
             S.k++;
@@ -621,8 +635,7 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
         } else {                                      // NOROOT on the first solve: label 1700
             if (S.iq <= 1) S.err = 1;
             S.ift = S.k;
-            if (!(S.k & 1)) S.out[S.k - 2] = (double)S.pend;      // an odd period's value was still waiting
-            for (int i = S.k; i <= kmax; i++) S.out[i - 1] = 0.0;
+            src.fill_zero(S, S.k, kmax);                  // cg(k..kmax) = 0, surfdisp96.f:348-354
             S.iq++; S.k = 1;
             if (S.iq > nmode) { src.done(S.err); S.ev = SWD_EV_FETCH; }
             else S.ev = SWD_EV_BEGIN_PERIOD;

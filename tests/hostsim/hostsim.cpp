@@ -41,6 +41,8 @@ struct OneTask {
     }
     void done(int e) { err = e; }
     void sphere(HostLay &lay, int mmax, int ifunc) { bh::swd_sphere(lay, mmax, ifunc); }
+    void put(bh::SwdState &S, int k, int kmax, float v) { bh::swd_put_direct(S, k, kmax, v); }
+    void fill_zero(bh::SwdState &S, int k, int kmax) { bh::swd_zero_direct(S, k, kmax); }
 };
 }  // namespace
 
