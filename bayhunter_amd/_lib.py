@@ -154,6 +154,7 @@ _SIGS = {
                                C.POINTER(SwdTarget), _vp, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     "bh_swd_batch_ordered": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                        C.POINTER(SwdTarget), _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "bh_swd_order_keys": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, C.c_int, _vp, _vp]),
     "bh_rf_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(RfParams)]),
     "bh_rf_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.POINTER(RfParams), _vp, C.c_int, _vp, C.c_size_t, _vp]),

@@ -330,6 +330,21 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     return rc;
 }
 
+int bh_swd_order_keys(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vs,
+                      double longest_period, int by_length, int *keys, void *stream)
+{
+    if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
+    if (model_stride < Lmax) return fail_arg("model_stride < Lmax");
+    if (B == 0) return BH_OK;
+    if (!nlay || !h || !vs || !keys) return fail_arg("NULL pointer");
+    if (!(longest_period > 0)) return fail_arg("longest_period must be positive");
+    int rc = ensure_device();
+    if (rc) return rc;
+    BH_HIP(bh::launch_order_keys(B, Lmax, model_stride, nlay, h, vs, 0.35 * 3.5 * longest_period, by_length, keys,
+                                 (hipStream_t)stream));
+    return BH_OK;
+}
+
 size_t bh_rf_workspace_bytes(int, int, const bh_rf_params *) { return 0; }
 
 static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vp,

@@ -54,6 +54,8 @@ struct VoronoiArgs {
     ModelPriorsDev pri;
 };
 hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream);
+hipError_t launch_order_keys(int B, int Lmax, int mstride, const int *nlay, const double *h, const double *vs,
+                             double reach, int by_length, int *keys, hipStream_t stream);
 hipError_t launch_division_selftest(long n, unsigned seed, int max_exp, unsigned long long *bad, hipStream_t stream);
 
 struct LikeTargetDev {

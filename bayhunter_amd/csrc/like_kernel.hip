@@ -331,6 +331,53 @@ hipError_t launch_division_selftest(long n, unsigned seed, int max_exp, unsigned
     return hipGetLastError();
 }
 
+// Sort key of the dispersion searches' processing order (engine.reorder): one thread per model.
+//   bits 24..30  127 - nlay          deepest models first (a wave's layer loop runs to its deepest model)
+//   bits 18..23  class of the predicted search length, longest first: a launch ends with lanes waiting
+//                for the last searches, so those should be short ones.  A search costs ~11 evaluations
+//                per period plus one per 0.005 km/s between its start value (0.855 c_R of the slowest
+//                layer) and the phase velocity at the longest period; predictor: a depth-kernel average
+//                of vs at that period (weights exp(-z/reach) h, reach = 0.35 * 3.5 km/s * period; the
+//                half-space counts with a thickness of one reach) minus 0.79 min(vs), classes of 0.15
+//   bits  0..17  S-wave travel time through the stack in 1/256 s: neighbours in a wave should be alike
+__global__ void order_key_kernel(int B, int Lmax, int mstride, const int *nlay, const double *h,
+                                 const double *vs, float reach, int by_length, int *keys)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int nl = nlay[b];
+    nl = nl < 1 ? 1 : (nl > Lmax ? Lmax : nl);
+    const double *hb = h + (long)b * mstride, *vb = vs + (long)b * mstride;
+    float tt = 0.f, z = 0.f, sw = 0.f, svw = 0.f, vmin = 1e9f;
+    for (int i = 0; i < nl; i++) {
+        const float hi = (float)hb[i], vi = (float)vb[i];
+        if (!(vi > 0.f)) { z += hi; continue; }           // water layer: no S wave
+        tt += hi / vi;
+        const bool hs = i == nl - 1;
+        const float zmid = hs ? z + 10.f : z + 0.5f * hi;
+        const float w = __expf(-zmid / reach) * (hs ? reach : hi);
+        sw += w; svw += vi * w;
+        vmin = fminf(vmin, vi);
+        z += hi;
+    }
+    int cls = 0;
+    if (by_length && sw > 0.f) {
+        const float span = 0.92f * svw / sw - 0.79f * vmin;
+        cls = (int)fminf(fmaxf(floorf((6.0f - span) / 0.15f), 0.f), 63.f);
+    }
+    const int depth = 127 - (nl > 127 ? 127 : nl);
+    const int t18 = (int)fminf(fmaxf(tt * 256.f, 0.f), 262143.f);
+    keys[b] = (depth << 24) | (cls << 18) | t18;
+}
+
+hipError_t launch_order_keys(int B, int Lmax, int mstride, const int *nlay, const double *h, const double *vs,
+                             double reach, int by_length, int *keys, hipStream_t stream)
+{
+    hipLaunchKernelGGL(order_key_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, Lmax, mstride, nlay, h, vs,
+                       (float)reach, by_length, keys);
+    return hipGetLastError();
+}
+
 hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream)
 {
     hipLaunchKernelGGL(voronoi_kernel, dim3((A.B + 255) / 256), dim3(256), 0, stream, A);

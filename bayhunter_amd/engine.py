@@ -5,6 +5,7 @@ src/Targets.py:314-347); the single-model plugin classes in plugins.py are
 thin views on it.  torch is used only for device memory and streams.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -134,6 +135,7 @@ class ForwardEngine(object):
         self._side = {}          # side stream: RF back-fills the SIMDs the SWD tail leaves idle
         self.overlap = True
         self.sort_ragged = True  # re-order ragged batches by layer count at upload
+        self.order_by_length = os.environ.get('BH_ORDER_BY_LENGTH', '1') != '0'   # (A/B switch)
 
     # -- helpers
     def _interp_tables(self, sp):
@@ -166,20 +168,29 @@ class ForwardEngine(object):
 
     def reorder(self, packed, nlay, ragged=None, depth=None):
         """DeviceModels for a packed [B, 4, Lmax] device tensor, with a processing order for large
-        batches: the lanes of a wave (and the teams sharing one) run their searches in lock step, so
-        neighbours should be alike.  Deepest models first (the layer loop runs to the deepest model
-        of a wave, and long searches should not form the tail), and within one depth by the S-wave
-        travel time through the stack, a cheap predictor of where the dispersion curve lies and how
-        long its search takes: 10 % at 524 288 ten-layer models (profiles/r01_divergence_probe.txt).
-        No data move; bh_swd_batch_ordered takes the permutation.  (`ragged` is accepted for
-        compatibility: the order is computed without a device round trip either way.)"""
+        batches.  Three keys, one sort (no data move; bh_swd_batch_ordered takes the permutation):
+          1. deepest models first: the layer loop of a wave runs to its deepest model;
+          2. longest searches first: persistent lanes run a handful of searches each, so a launch ends
+             with a tail in which lanes wait for the last searches -- shorter if those are short ones.
+             A search costs ~11 evaluations per period plus one per 0.005 km/s between the start value
+             (0.855 c_R of the slowest layer) and the phase velocity at the longest period; the
+             predictor is a depth-kernel average of vs at that period minus 0.79 min(vs), in classes of
+             0.15 km/s (5 % at 524 288 ten-layer models, tools/divergence_probe.py);
+          3. within a class by the S-wave travel time through the stack: the lanes of a wave run in
+             lock step, so neighbours should be alike (10 % over a random order,
+             profiles/r01_divergence_probe.txt).
+        (`ragged` is accepted for compatibility.)"""
         order = None
         if self.sort_ragged and self.swd and packed.shape[0] > ORDER_MIN:
-            H, VS = packed[:, 0, :], packed[:, 2, :]
-            tt = torch.where(VS > 0, H / VS.clamp_min(1e-300), torch.zeros_like(H)).sum(dim=1)
-            # one sort: depth (descending) is the major key, travel time (< 1e4 s) the minor one
-            key = (tt.clamp(0., 9.9e3) - nlay.to(torch.float64) * 1.0e4).to(torch.float32)
-            order = torch.argsort(key).to(torch.int32)
+            B, L = packed.shape[0], packed.shape[2]
+            keys = torch.empty(B, dtype=torch.int32, device=self.device)
+            tmax = max(float(sp.periods.max()) for sp in self.swd)
+            st = torch.cuda.current_stream(self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.bh_swd_order_keys(
+                    B, L, 4 * L, nlay.data_ptr(), packed[:, 0, :].data_ptr(), packed[:, 2, :].data_ptr(),
+                    tmax, 1 if self.order_by_length else 0, keys.data_ptr(), C.c_void_p(st.cuda_stream)))
+            order = torch.argsort(keys).to(torch.int32)
         return DeviceModels(packed, nlay, order, depth)
 
     def alloc_out(self, B):

@@ -127,6 +127,14 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
                          int out_stride, int *err, const int *order, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* Sort keys for that order (device pointers; keys: int[B]): sorting the models by ascending key puts
+ * the deepest first, within a depth the predicted longest searches first (by_length != 0; a launch
+ * ends with lanes waiting for the last searches, which should be short ones) and within such a class
+ * the models by their S-wave travel time.  longest_period: the longest period of the targets [s].
+ * order = argsort(keys) is left to the caller (any device sort; bayhunter_amd/engine.py has one). */
+int bh_swd_order_keys(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vs,
+                      double longest_period, int by_length, int *keys, void *stream);
+
 /* ---- batched receiver functions (device pointers) --------------------------------------- */
 /* qp/qs may be NULL: 500 / 225 like rfmini_modrf.py:119-120.  Output: the first nout samples of
  * the RF trace at out[b*out_stride + out_off + i].  NaN propagates like in the reference. */

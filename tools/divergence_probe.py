@@ -47,11 +47,19 @@ def csur(T):
     w = np.exp(-zmid / (0.35 * 3.5 * T)) * hh
     return 0.92 * (VS * w).sum(axis=1) / w.sum(axis=1)
 c1, c20, c41 = csur(1.0), csur(20.0), csur(41.0)
+span = c41 - c1                    # ~ number of grid steps of all scans together: a search-length predictor
+vsmin = np.where(VS > 0, VS, 1e9).min(axis=1)
+span2 = c41 - 0.79 * vsmin        # + the first period's scan from cc = 0.855 c_R(slowest layer)
 keys = {
     'S travel time (ascending)': (tt,),
-    'S travel time (descending)': (-tt,),
-    'travel time in 64 bins, then surrogate c(1)': (c1, bins(tt, 64)),
-    'travel time in 64 bins descending, then surrogate c(1)': (c1, -bins(tt, 64)),
+    'span in 8 bins (longest first), then travel time': (tt, -bins(span, 8)),
+    'span in 16 bins (longest first), then travel time': (tt, -bins(span, 16)),
+    'span in 32 bins (longest first), then travel time': (tt, -bins(span, 32)),
+    'span2 in 8 bins (longest first), then travel time': (tt, -bins(span2, 8)),
+    'span2 in 16 bins (longest first), then travel time': (tt, -bins(span2, 16)),
+    'span2 in 32 bins (longest first), then travel time': (tt, -bins(span2, 32)),
+    'span2 descending': (-span2,),
+    'span2 in 16 bins (longest first), then c(1)': (c1, -bins(span2, 16)),
 }
 for tag, ks in keys.items():
     o = np.lexsort(ks)
