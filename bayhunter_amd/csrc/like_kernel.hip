@@ -31,60 +31,71 @@ __device__ __forceinline__ double wave_sum(double v)
 // Writes q and sum(d^2) per model into `gq` [B][2]; like_kernel picks them up.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// NT column tiles per pass (NT*8 accumulator VGPRs); wider targets take several passes
+// One workgroup = 4 waves = 64 models (16 per wave).  R^-1 is streamed through LDS in chunks of
+// GQ_KC rows that the four waves share (round 1 had every wave fetch its own fragments from L2 with
+// 256 VGPRs and one wave per SIMD: latency-bound at 13 TFLOP/s); the next chunk is loaded into the
+// other buffer while the MFMAs of the current one issue.  NT column tiles per pass (NT*8
+// accumulator VGPRs); wider targets take several passes.
+enum { GQ_KC = 16, GQ_WAVES = 4 };
 template <int NT>
-__global__ __launch_bounds__(64) void gauss_q_kernel(LikeArgs A, int t, double *gq)
+__global__ __launch_bounds__(64 * GQ_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void gauss_q_kernel(LikeArgs A, int t, double *gq)
 {
+    extern __shared__ double rbuf[];                  // [2][GQ_KC][NT*16]
+    constexpr int NP = NT * 16;
     const LikeTargetDev tg = A.tg[t];
-    const long b0 = (long)blockIdx.x * 16;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long b0 = ((long)blockIdx.x * GQ_WAVES + wave) * 16;
     const int n = tg.n;
     const double *R = A.aux + tg.aux_off;
     const int mrow = lane & 15, kq = lane >> 4;
     const long bm = b0 + mrow;
     const bool mvalid = bm < A.B;
-    const double *drow = A.out + (mvalid ? bm : b0) * (long)A.out_stride + tg.off;
+    const double *drow = A.out + (mvalid ? bm : 0) * (long)A.out_stride + tg.off;
     const double *yobs = A.yobs + tg.off;
     double q[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     const int ntiles = (n + 15) / 16;
+    const int nchunk = (n + GQ_KC - 1) / GQ_KC;
     for (int tb = 0; tb < ntiles; tb += NT) {
         double4_t acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; i++) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
-        // software pipeline: the fragments of k-step s+1 are in flight while the NT MFMAs of step s
-        // issue (one wave per SIMD: nothing else hides the L2 latency of R^-1)
-        double an, bn[NT];
-        {
-            const int k = kq;
-            an = (mvalid && k < n) ? drow[k] - yobs[k] : 0.0;
-#pragma unroll
-            for (int i = 0; i < NT; i++) {
-                const int col = (tb + i) * 16 + mrow;
-                bn[i] = (k < n && col < n) ? R[(long)k * n + col] : 0.0;
+        const int col0 = tb * 16;
+        // chunk c of R^-1 (rows c*KC .., columns col0 .. col0+NP) -> rbuf[c & 1], zero padded
+        auto load_chunk = [&](int c) {
+            double *dst = rbuf + (c & 1) * (GQ_KC * NP);
+#pragma unroll 4
+            for (int e = tid; e < GQ_KC * NP; e += 64 * GQ_WAVES) {
+                const int r = e / NP, cc = e - r * NP;
+                const int k = c * GQ_KC + r, col = col0 + cc;
+                dst[e] = (k < n && col < n) ? R[(long)k * n + col] : 0.0;
             }
-        }
-        for (int k0 = 0; k0 < n; k0 += 4) {
-            const double a = an;
-            double bv[NT];
+        };
+        load_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < nchunk; c++) {
+            if (c + 1 < nchunk) load_chunk(c + 1);       // other buffer: free since the last barrier
+            const double *src = rbuf + (c & 1) * (GQ_KC * NP);
+            double av[GQ_KC / 4];
 #pragma unroll
-            for (int i = 0; i < NT; i++) bv[i] = bn[i];
-            const int k = k0 + 4 + kq;
-            an = (mvalid && k < n) ? drow[k] - yobs[k] : 0.0;
-#pragma unroll
-            for (int i = 0; i < NT; i++) {
-                const int col = (tb + i) * 16 + mrow;
-                bn[i] = (k < n && col < n) ? R[(long)k * n + col] : 0.0;
+            for (int ks = 0; ks < GQ_KC / 4; ks++) {
+                const int k = c * GQ_KC + ks * 4 + kq;
+                av[ks] = (mvalid && k < n) ? drow[k] - yobs[k] : 0.0;
             }
+#pragma unroll 1
+            for (int ks = 0; ks < GQ_KC / 4; ks++) {
+                const double *row = src + (ks * 4 + kq) * NP + mrow;
 #pragma unroll
-            for (int i = 0; i < NT; i++)
-                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[i], acc[i], 0, 0, 0);
+                for (int i = 0; i < NT; i++)
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], row[i * 16], acc[i], 0, 0, 0);
+            }
+            __syncthreads();
         }
         // lane holds Y[model kq + 4r][col (tb+i)*16 + mrow]; dot with D over these columns
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const long bmod = b0 + kq + 4 * r;
             const bool ok = bmod < A.B;
-            const double *dr = A.out + (ok ? bmod : b0) * (long)A.out_stride + tg.off;
+            const double *dr = A.out + (ok ? bmod : 0) * (long)A.out_stride + tg.off;
 #pragma unroll
             for (int i = 0; i < NT; i++) {
                 const int col = (tb + i) * 16 + mrow;
@@ -391,12 +402,13 @@ hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
             if (A.tg[t].cov == 3)
             {
                 const int nt = (A.tg[t].n + 15) / 16;
-                const dim3 g((A.B + 15) / 16), b(64);
+                const dim3 g((A.B + 16 * GQ_WAVES - 1) / (16 * GQ_WAVES)), b(64 * GQ_WAVES);
                 double *gq = A.gq + (long)t * A.B * 2;
-                if (nt <= 4) hipLaunchKernelGGL(gauss_q_kernel<4>, g, b, 0, stream, A, t, gq);
-                else if (nt <= 8) hipLaunchKernelGGL(gauss_q_kernel<8>, g, b, 0, stream, A, t, gq);
-                else if (nt == 13) hipLaunchKernelGGL(gauss_q_kernel<13>, g, b, 0, stream, A, t, gq);
-                else hipLaunchKernelGGL(gauss_q_kernel<16>, g, b, 0, stream, A, t, gq);
+                const int NTsel = nt <= 4 ? 4 : nt <= 8 ? 8 : 13;          // wider targets: passes of 13 tiles
+                const size_t lds = (size_t)2 * GQ_KC * NTsel * 16 * sizeof(double);   // <= 64 KiB
+                if (NTsel == 4) hipLaunchKernelGGL(gauss_q_kernel<4>, g, b, lds, stream, A, t, gq);
+                else if (NTsel == 8) hipLaunchKernelGGL(gauss_q_kernel<8>, g, b, lds, stream, A, t, gq);
+                else hipLaunchKernelGGL(gauss_q_kernel<13>, g, b, lds, stream, A, t, gq);
             }
     }
     size_t lds = (size_t)LIKE_M * nmax * sizeof(double);
