@@ -178,6 +178,9 @@ struct TeamSrc {
     long b;
     unsigned int *queue;     // nullptr: this team runs search `b` only; else teams pull searches
                              // from the per-target counter until it runs past the batch
+    float *res;              // wide teams: the search's results wait here (LDS, [nper]) and are written
+                             // as one coalesced row at the end -- no global store inside the loop, so
+                             // the barriers of a round never wait for one; nullptr: store directly
     __device__ __forceinline__ int next(TeamLay &lay, double *&out, double *&cws, double *&cbws)
     {
         const int L = A.Lmax;
@@ -216,15 +219,23 @@ struct TeamSrc {
     __device__ __forceinline__ void done(int err)
     {
         if (lane == 0) A.err[b * A.ntargets + t] = err;
+        if (res && lane < tg.nper)           // (lane 0 wrote res[]: same wave, program order)
+            A.out[b * A.out_stride + tg.out_off + lane] = (double)res[lane];
     }
     // every lane of the team runs the driver: one of them stores
     __device__ __forceinline__ void put(SwdState &S, int k, int kmax, float v)
     {
+        if (res) { if (lane == 0) res[k - 1] = v; return; }
         if (lane == 0) swd_put_direct(S, k, kmax, v);
         else if ((k & 1) && k != kmax) S.pend = v;      // (keep the state identical on all lanes)
     }
     __device__ __forceinline__ void fill_zero(SwdState &S, int k, int kmax)
     {
+        if (res) {
+            if (lane == 0)
+                for (int i = k; i <= kmax; i++) res[i - 1] = 0.f;
+            return;
+        }
         if (lane == 0) swd_zero_direct(S, k, kmax);
     }
     // The team shares one copy of the model: the lanes of a wave transform it in lock step (every
@@ -277,7 +288,7 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
     const int per_team = nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * A.Lmax + 1) / 2;
     double *mats = tlds + (long)sub * per_team, *trials = mats + (long)nm * SWD_NCA, *dels = trials + SWD_TEAM_NT;
     TeamLay lay{(float *)(dels + SWD_TEAM_NT), A.Lmax};
-    TeamSrc src{A, tg, t, lane, TEAM, 0, (long)blockIdx.x, A.counters + t};
+    TeamSrc src{A, tg, t, lane, TEAM, 0, (long)blockIdx.x, A.counters + t, nullptr};
     const double *per = A.periods + tg.per_off;
     SwdState S;
     swd_state_init(S);
@@ -428,9 +439,17 @@ __device__ __forceinline__ void quad_apply(double e[5], const QuadCols &q)
     e[2] = dpp_quad<0xAA>(enA);
     e[3] = dpp_quad<0xFF>(enA);
 }
+// one layer's values held in registers (whatever index is asked for)
+struct OneLay {
+    float dd, aa, bb, rr;
+    __device__ __forceinline__ float d(int) const { return dd; }
+    __device__ __forceinline__ float a(int) const { return aa; }
+    __device__ __forceinline__ float b(int) const { return bb; }
+    __device__ __forceinline__ float rho(int) const { return rr; }
+};
 template <class Lay>
-__device__ __forceinline__ double swd_teamw_chain_quad(const Lay &lay, const SwdState &S, double qc, double qom,
-                                                       const double *m0)
+__device__ __forceinline__ double swd_teamw_chain_quad(const Lay &lay, const OneLay &half, const SwdState &S,
+                                                       double qc, double qom, const double *m0)
 {
     const int i = threadIdx.x & 3;
     const int nlm = S.mmax - S.llw;
@@ -438,7 +457,7 @@ __device__ __forceinline__ double swd_teamw_chain_quad(const Lay &lay, const Swd
     double omega = qom;
     if (omega < 1.0e-4) omega = 1.0e-4;
     double e[5];
-    swd_ray_halfspace(lay, S.mmax, wvno, wvno * wvno, omega, e);
+    swd_ray_halfspace(half, S.mmax, wvno, wvno * wvno, omega, e);
     // two layers per trip, their columns loaded one layer ahead into alternating register sets
     const double *p = m0 + (long)(nlm - 1) * SWD_MAT;
     QuadCols qa, qb;
@@ -467,32 +486,40 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     const int nm = A.Lmax > NL ? A.Lmax : NL;
     double *mats = tlds, *dels = mats + (long)nm * SWD_MAT, *perl = dels + SWD_TEAMW_NT, *nevt = perl + BH_NP;
     double *tcl = nevt + 24 * W, *toml = tcl + SWD_TEAMW_NT;
-    TeamLay lay{(float *)(toml + SWD_TEAMW_NT), A.Lmax};
+    float *res = (float *)(toml + SWD_TEAMW_NT);                 // [BH_NP] staged results
+    TeamLay lay{res + BH_NP, A.Lmax};
     // every wave runs the control code for itself: a Neville table per wave (the waves are not in
     // step inside a phase)
     NevMem nv{nevt + 24 * wave, nevt + 24 * wave + 12};
     for (int k = lane; k < tg.nper; k += NL) perl[k] = A.periods[tg.per_off + k];   // (TeamSrc::next syncs)
-    TeamSrc src{A, tg, t, lane, NL, 0, (long)blockIdx.x, nullptr};
+    TeamSrc src{A, tg, t, lane, NL, 0, (long)blockIdx.x, nullptr, res};
     SwdState S;
     swd_state_init(S);
+    TeamwNext nxt{-1, -1, 0.0};
     BH_TP_DECL;
     long rounds = 0;
-    int nlm_seen = -1, cap = 1, ja = 0, ra = 0;
+    const double *out_seen = nullptr;
+    int cap = 1, ja = 0, ra = 0;
+    OneLay mine{0.f, 0.f, 0.f, 0.f}, half{0.f, 0.f, 0.f, 0.f};
     for (;;) {
         swd_driver(S, lay, src, tg, perl, A.B, true);
         if (S.st == SWD_ST_DONE) break;
         BH_TP(0);
         const int nlm = S.mmax - S.llw;
-        if (nlm != nlm_seen) {            // a new model: slots per round, and which (trial, layer) this lane assembles
-            nlm_seen = nlm;
+        if (S.out != out_seen) {          // a new model: slots per round, and which (trial, layer) this lane assembles
+            out_seen = S.out;
             cap = nlm > 0 ? NL / nlm : SWD_TEAMW_NT;
             if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;            // one quad per Rayleigh trial
             if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
             if (cap < 1) cap = 1;
             ja = (cap > 1 && nlm > 0) ? lane / nlm : 0;
             ra = lane - ja * nlm;
+            // this lane's layer and the half-space, read from the shared copy once per model
+            const int i0 = S.llw - 1 + (ra < nlm ? ra : 0), ih = S.mmax - 1;
+            mine = OneLay{lay.d(i0), lay.a(i0), lay.b(i0), lay.rho(i0)};
+            half = OneLay{lay.d(ih), lay.a(ih), lay.b(ih), lay.rho(ih)};
         }
-        const TeamwRound R = swd_teamw_round(S, tg, perl, cap);
+        const TeamwRound R = swd_teamw_round(S, tg, perl, cap, nxt);
         const int nt = R.nt;
         double mc, mom;                                                 // slot wl of the plan
         swd_teamw_trial(R, S, wl < nt ? wl : 0, &mc, &mom);
@@ -504,7 +531,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             if (ja < nt && nlm > 0) {
                 const double ac = tcl[ja];
                 if (ac == ac)                                           // (NaN: a scan slot out of bounds)
-                    swd_teamw_assemble_one(lay, tg.iwave, S, ra, ac, toml[ja], mats + (long)lane * SWD_MAT);
+                    swd_teamw_assemble_one(mine, tg.iwave, S, ra, ac, toml[ja], mats + (long)lane * SWD_MAT);
             }
         } else {
             for (int r = lane; r < nlm; r += NL)
@@ -515,7 +542,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         __syncthreads();
         BH_TP(2);
         if (tg.iwave == 2) {
-            const double del = swd_teamw_chain_quad(lay, S, qc, qom, mats + (long)(qvalid ? jq : 0) * nlm * SWD_MAT);
+            const double del = swd_teamw_chain_quad(lay, half, S, qc, qom, mats + (long)(qvalid ? jq : 0) * nlm * SWD_MAT);
             if (qvalid && (wl & 3) == 0) dels[jq] = del;
         } else if (lane < nt) {
             dels[lane] = swd_teamw_chain_one(lay, 1, S, mc, mom, mats + (long)lane * nlm * SWD_MAT);
@@ -691,7 +718,7 @@ size_t swd_team_lds_bytes(int Lmax, int team)
 {
     if (team >= SWD_T) {           // wide teams: mats[max(Lmax, lanes)][SWD_MAT], dels, periods, layer stack
         const int nm = Lmax > team ? Lmax : team;
-        return ((size_t)nm * SWD_MAT + 3 * SWD_TEAMW_NT + BH_NP + 24 * (team / SWD_T) + (4 * Lmax + 1) / 2) * sizeof(double);
+        return ((size_t)nm * SWD_MAT + 3 * SWD_TEAMW_NT + BH_NP + 24 * (team / SWD_T) + BH_NP / 2 + (4 * Lmax + 1) / 2) * sizeof(double);
     }
     const int nsub = SWD_T / team;
     const int nm = Lmax > team ? Lmax : team;

@@ -237,8 +237,13 @@ struct TeamwRound {
     double base, oms;             // the point the scan steps away from, omega of the scan
 };
 
+// omega of the search that follows the current one, kept across the rounds of a search (k, pass)
+struct TeamwNext {
+    int k, pass;
+    double oms;
+};
 BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, const double *BH_RESTRICT per,
-                                  int cap)
+                                  int cap, TeamwNext &nx)
 {
     const double dc = (double)0.005f;
     TeamwRound R;
@@ -266,19 +271,24 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
         // case -- fundamental mode, no workspace -- is predicted)
         const double TWOPI = 2.0 * 3.141592653589793, one = 1.0e-2, onea = 1.5;
         const float h = 0.005f;
+        const bool fresh = nx.k != S.k || nx.pass != S.pass;
         if (tg.igr > 0 && S.pass == 0) {            // second solve of the pair, surfdisp96.f:282-294
-            R.oms = TWOPI / (double)S.t1b;
+            if (fresh) nx.oms = TWOPI / (double)S.t1b;
             R.base = S.ceval - onea * dc;
             clows = 0.0 + one * dc;
         } else {                                    // next period, surfdisp96.f:231-239,268-271
             const int k2 = S.k + 1;
             if (k2 > tg.nper || k2 >= S.ift) return R;
-            double t1 = per[k2 - 1];
-            if (tg.igr > 0) t1 = (double)(float)(t1 / (double)(1.f + h));
-            R.oms = TWOPI / t1;
+            if (fresh) {
+                double t1 = per[k2 - 1];
+                if (tg.igr > 0) t1 = (double)(float)(t1 / (double)(1.f + h));
+                nx.oms = TWOPI / t1;
+            }
             R.base = ((S.pass == 0) ? S.ceval : S.ck) - onea * dc;
             clows = S.cc;
         }
+        nx.k = S.k; nx.pass = S.pass;
+        R.oms = nx.oms;
         R.entry = R.nt++;
         scan_ok = true;
     }

@@ -144,6 +144,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
     bh::swd_state_init(S);
     double nx[12], ny[12];
     bh::NevMem nv{nx, ny};
+    bh::TeamwNext nxt{-1, -1, 0.0};
     bh::swd_nev_init(nv);
     long nc = 0, ns = 0, nr = 0;
     for (;;) {
@@ -152,7 +153,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         const int nlm = S.mmax - S.llw;
         int cap = nlm > 0 ? nlanes / nlm : NT;
         if (cap > nlanes / 4) cap = nlanes / 4;           // one quad per Rayleigh trial
-        const bh::TeamwRound R = bh::swd_teamw_round(S, tg, t, cap);
+        const bh::TeamwRound R = bh::swd_teamw_round(S, tg, t, cap, nxt);
         const int nt = R.nt;
         if (nt < 1 || nt > NT || nt > (cap > 1 ? cap : 1)) return -100;      // layout invariants
         for (int j = 0; j < nt; j++) bh::swd_teamw_trial(R, S, j, &tc[j], &tom[j]);
