@@ -181,6 +181,8 @@ np.savez(sys.argv[1], **r)
             with np.load(path) as z:
                 res.append({k: z[k] for k in z.files})
     a, b = res
+    if all(np.array_equal(a[k], b[k]) for k in ('ph', 'gr', 'lph')):
+        pytest.skip('GLIBC_TUNABLES did not switch the libm variant on this host (identical results)')
     for name, tol in (('ph', TOL_PHASE_REL), ('gr', TOL_GROUP_REL)):
         assert np.array_equal(a[name + '_err'], b[name + '_err'])
         ok = a[name + '_err'] == 0
