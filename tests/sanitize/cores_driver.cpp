@@ -2,7 +2,8 @@
 // includes swd_core.h, swd_team.h, rf_core.h under BH_HOSTSIM): built with
 // g++ -fsanitize=address,undefined by tests/test_sanitizers.py and run over pseudo-random models --
 // 1 to 100 layers, low-velocity zones, water layer, all wave types, modes 1-3, flat/spherical,
-// 1 to 60 periods, the team replay at several widths, receiver functions at four transform lengths
+// 1 to 60 periods, the team replays at several widths (which must agree bitwise), receiver functions at
+// four transform lengths
 // and with layer-dependent Q.  Out-of-range indexing of the layer images, the Neville tables or the
 // FFT buffers, and undefined arithmetic, would show here; GPU sanitizers are not available.
 #include <cmath>
@@ -54,6 +55,19 @@ int main()
                                        cg.data(), widths[trial % 5], &nc, &ns, &nr);
                 for (double x : cg) acc += x;
                 calls += nr + e;
+                // the wide-team replay (speculation across root searches, value-matched consumption,
+                // NevMem tables, slot layout): 64, 128, 256, 512 virtual lanes
+                static const int wide[4] = {64, 128, 256, 512};
+                std::vector<double> cg2(nper);
+                int e2 = hs_surfdisp96_teamw(h.data(), vp.data(), vs.data(), rho.data(), L, fl, iw, mode, ig, nper,
+                                             per.data(), cg2.data(), wide[trial % 4], &nc, &ns, &nr);
+                if (e2 != e) { std::printf("wide replay: err %d vs %d (trial %d)\n", e2, e, trial); return 1; }
+                for (int k = 0; k < nper; k++)
+                    if (!(cg2[k] == cg[k]) && !(cg2[k] != cg2[k] && cg[k] != cg[k])) {
+                        std::printf("wide replay differs (trial %d, period %d)\n", trial, k);
+                        return 1;
+                    }
+                calls += nr;
             }
         if (vsd[0] > 0 && trial % 2 == 0) {
             static const int ns[4] = {64, 256, 512, 2048};

@@ -357,7 +357,7 @@ def test_headline_size_order_invariance(lib, oracle):
     assert np.abs(o[:, 21:] - oracle.rf_batch(H[sl], VP[sl], VS[sl], RHO[sl], nl[sl])).max() <= TOL_RF
 
 
-@pytest.fixture(params=['team', 'team32', 'team16', 'team8', 'team128', 'team256'])
+@pytest.fixture(params=['team', 'team32', 'team16', 'team8', 'team128', 'team256', 'team512'])
 def team_mode(lib, request):
     from bayhunter_amd import _lib
     _lib.set_swd_kernel(request.param)
@@ -391,7 +391,7 @@ def test_team_and_lane_kernels_agree_bitwise(lib, oracle):
              (draw_models(6, 100, seed=14, zmax=300.0, thickmin=0.05), dict())]
     for (H, VP, VS, RHO, nl), kw in cases:
         res = {}
-        for mode in ('lane', 'team', 'team32', 'team16', 'team8', 'team128', 'team256'):
+        for mode in ('lane', 'team', 'team32', 'team16', 'team8', 'team128', 'team256', 'team512'):
             _lib.set_swd_kernel(mode)
             try:
                 eng = _engine([r[0] for r in REFS], per, **kw)
@@ -399,7 +399,7 @@ def test_team_and_lane_kernels_agree_bitwise(lib, oracle):
                 res[mode] = (out.cpu().numpy(), err.cpu().numpy())
             finally:
                 _lib.set_swd_kernel('auto')
-        for mode in ('team', 'team32', 'team16', 'team8', 'team128', 'team256'):
+        for mode in ('team', 'team32', 'team16', 'team8', 'team128', 'team256', 'team512'):
             assert np.array_equal(res['lane'][1], res[mode][1]), mode
             assert np.array_equal(res['lane'][0], res[mode][0]), mode
         if not kw:

@@ -50,6 +50,34 @@ def test_swd_team_replay_bitexact(oracle, hostsim, L, srt):
         assert tot_rounds < 0.62 * tot_calls      # speculation pays when >= 6 trials fit a round
 
 
+@pytest.mark.parametrize('L,srt', [(1, True), (2, True), (5, True), (10, False), (15, True), (31, False), (80, True)])
+def test_swd_wide_team_replay_bitexact(oracle, hostsim, L, srt):
+    """Wide teams (swd_teamw_*: slot layout, bisection candidates, speculation across the end of a root
+    search, value-matched consumption with run fast-forward, Neville tables in memory): same values,
+    err flags and number of CONSUMED evaluations as the reference for 64/128/256 lanes; the replay
+    itself checks the plan's invariants.  Rounds per period roughly halve against the round-1 scheme."""
+    kw = dict(zmax=300.0, thickmin=0.05) if L > 40 else {}
+    H, VP, VS, RHO, nl = draw_models(5, L, seed=1700 + L + int(srt), sorted_vs=srt, **kw)
+    per = np.linspace(1, 41, 21)
+    new = old = 0
+    for name, iw, ig in REFS:
+        for mode, fl in ((1, 0), (2, 0), (3, 1)):
+            for b in range(5):
+                n = nl[b]
+                a, e1, n1 = oracle.swd(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], per, iw, ig, mode, fl, count=True)
+                for nlanes in (64, 128, 256):
+                    r, e2, n2, nspec, nrounds = hostsim.swd_team(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], per,
+                                                                  iw, ig, mode, fl, nlanes, wide=True)
+                    assert e2 >= 0, 'plan invariant %d violated' % e2
+                    assert e1 == e2 and n1 == n2 and nspec >= n2
+                    assert np.array_equal(a, r)
+                    if nlanes == 64 and mode == 1 and fl == 0:
+                        new += nrounds
+                        old += hostsim.swd_team(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], per, iw, ig, 1, 0, 64)[4]
+    if 2 <= L <= 5:
+        assert new < 0.6 * old
+
+
 def test_swd_nan_model_terminates(hostsim):
     """A NaN model must not spin forever (the reference would); it ends as 'no root'."""
     h = np.array([5., 10., 0.])
