@@ -433,7 +433,9 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
     const double dc = (double)0.005f;
     int used = 0;
     while (used < R.nt) {
-        const int j = vals.find(S.omega, S.ceval);
+        // slot 0 IS the pending evaluation (no comparison: a NaN model has a NaN trial velocity, which
+        // equals nothing, and the search must still advance -- to its bracketing step cap -- and end)
+        const int j = used == 0 ? 0 : vals.find(S.omega, S.ceval);
         vals.probe(4);
         if (j < 0) break;
         if (S.st == SWD_ST_B && S.idir > 0 && R.nscan > 0 && j >= R.scan0) {

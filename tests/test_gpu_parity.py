@@ -627,3 +627,32 @@ def test_model_deeper_than_the_launch_is_flagged_not_truncated(lib, oracle):
         out, err = out.cpu().numpy(), err.cpu().numpy()
         assert np.all(err[bad] == 2) and np.all(np.isnan(out[bad])), mode
         assert np.array_equal(err[good, 0], werr[good]) and np.array_equal(out[good, :21][werr[good] == 0], want[good][werr[good] == 0]), mode
+
+
+@pytest.mark.parametrize('kernel', ['lane', 'team', 'team256', 'team16'])
+def test_nan_models_end_in_every_kernel_form(lib, kernel):
+    """A NaN model: one with a NaN top layer (finite start value, NaN period equation) and one that is
+    NaN throughout (NaN start value, so every trial velocity is NaN and equals nothing).  The reference
+    would scan forever on the second; every kernel form must run into the bracketing step cap, report
+    "no root" (err = 1, zero row), and leave the neighbours in the batch untouched."""
+    from bayhunter_amd import _lib
+    per = np.linspace(1, 41, 5)
+    H, VP, VS, RHO, nl = draw_models(6, 4, seed=71)
+    clean = [a.copy() for a in (H, VP, VS, RHO)]
+    VS[2, 0] = np.nan; VP[2, 0] = np.nan
+    VS[4, :] = np.nan; VP[4, :] = np.nan; RHO[4, :] = np.nan
+    eng = _engine(['rdispph', 'ldispph'], per)
+    _lib.set_swd_kernel(kernel)
+    try:
+        out, err = eng.run(H, VP, VS, RHO, nl)
+        ref, rerr = eng.run(*clean, nl)
+        out, err, ref, rerr = (x.cpu().numpy() for x in (out, err, ref, rerr))
+    finally:
+        _lib.set_swd_kernel('auto')
+    for b in (2, 4):                 # "no root" (zero row, err 1) or NaN values: never a plausible curve
+        for t in (0, 1):
+            row = out[b, 5 * t:5 * t + 5]
+            assert (err[b, t] == 1 and np.all(row == 0.0)) or np.isnan(row).any(), (b, t, row, err[b])
+    assert np.all(err[4] == 1) and np.all(out[4] == 0.0)          # all-NaN model: the step cap ends the scan
+    ok = [0, 1, 3, 5]
+    assert np.array_equal(out[ok], ref[ok]) and np.array_equal(err[ok], rerr[ok])

@@ -84,6 +84,13 @@ def test_swd_nan_model_terminates(hostsim):
     vs = np.array([3.0, np.nan, 4.5])
     cg, err, ncalls = hostsim.swd(h, vs * 1.73, vs, vs * 1.73 * .32 + .77, np.linspace(1, 41, 5), 2, 0)
     assert err == 1 and np.all(cg == 0.0) and ncalls <= 100003
+    # NaN throughout: the start value and every trial velocity are NaN (equal to nothing); the wide-team
+    # replay must still consume its pending evaluation every round and run into the step cap
+    nanv = np.full(3, np.nan)
+    for wide, nlanes in ((False, 64), (True, 64), (True, 256)):
+        cg, err, ncalls, nspec, nrounds = hostsim.swd_team(h, nanv, nanv, nanv, np.linspace(1, 41, 3), 2, 0,
+                                                           nlanes=nlanes, wide=wide)
+        assert err == 1 and np.all(cg == 0.0) and 100000 <= ncalls <= 100003, (wide, nlanes, err, ncalls)
 
 
 @pytest.mark.parametrize('wn', [0, 1])
