@@ -157,7 +157,8 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         const int nt = R.nt;
         if (nt < 1 || nt > NT || nt > (cap > 1 ? cap : 1)) return -100;      // layout invariants
         for (int j = 0; j < nt; j++) bh::swd_teamw_trial(R, S, j, &tc[j], &tom[j]);
-        if (tc[0] != S.ceval || tom[0] != S.omega) return -101;
+        auto same = [](double a, double b) { return a == b || (a != a && b != b); };
+        if (!same(tc[0], S.ceval) || !same(tom[0], S.omega)) return -101;
         for (int i = 0; i + 1 < R.nscan; i++) {           // scan trials: consecutive grid points
             const int j0 = R.scan0 + i * R.stride, j1 = j0 + R.stride;
             if (j1 < nt && tc[j1] == tc[j1] && tc[j1] != tc[j0] + (double)0.005f) return -102;
