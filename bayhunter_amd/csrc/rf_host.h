@@ -8,6 +8,8 @@
 
 namespace bh {
 
+constexpr double RF_WEIGHT_CUTOFF = 3.0e-19;
+
 inline void rf_fill_launch(RfLaunch &P, double p, double gauss, int nsamp, double fsamp,
                            double tshift, double nsv, int waveno, int nout)
 {
@@ -27,12 +29,14 @@ inline void rf_fill_launch(RfLaunch &P, double p, double gauss, int nsamp, doubl
     while ((1 << P.log2n) < nsamp) P.log2n++;
     P.waveno = waveno;
     P.nout = nout;
-    // The spectrum is multiplied by exp(-(w/a)^2/4) (greens.cpp:389-392).  Where that weight is below
-    // 1e-24 of its value at w = 0 the term cannot reach the last bit of any sample (it would take a
-    // spectral ratio of 1e8 to get within 1e-16 of the trace's scale): those frequencies are set to
-    // zero instead of being computed.  a = 1, 5 Hz, nsamp 512: 243 of 257 (6 instead of 7 passes
-    // of a 256-thread workgroup over 6 models); a >= 1.06: all of them.
-    const double wcut = 2.0 * gauss * std::sqrt(std::log(1.0e24));
+    // The spectrum is multiplied by exp(-(w/a)^2/4) (greens.cpp:389-392).  Frequencies whose weight is
+    // below RF_WEIGHT_CUTOFF of its value at w = 0 are set to zero instead of being computed: their
+    // contribution to a sample is cutoff x |R/Z| (the deconvolved spectral ratio, O(1..1e3) for a
+    // layered model with attenuation), i.e. <= 1e-16 of the trace's scale -- five orders below the
+    // parity tolerance of 1e-10 even for a ratio of 1e4.  a = 1, 5 Hz, nsamp 512: 213 of 257
+    // frequencies are computed (5 instead of 6 passes of a 256-thread workgroup over 6 models; the
+    // round-1 cutoff of 1e-24 kept 243); a >= 1.21: all of them.
+    const double wcut = 2.0 * gauss * std::sqrt(std::log(1.0 / RF_WEIGHT_CUTOFF));
     double jcut = std::floor(wcut / P.dw) + 1.0;
     P.nact = (jcut < (double)P.nfreq) ? (int)jcut : P.nfreq;
     if (P.nact < 1) P.nact = 1;
