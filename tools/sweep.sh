@@ -10,5 +10,5 @@ python - <<'PY'
 import json
 for l in open('gpurun_out/sweep.jsonl'):
     r=json.loads(l)
-    print(r['config']['models_per_gpu'], '%.3e evals/s'%r['value'], 'step %.2f ms'%r['ms_per_step'], 'swd %.2f ms rf %.2f ms'%(r['kernels_ms']['swd_kernel'], r['kernels_ms']['rf_kernel']), 'fp64 frac %.3f'%r['fp64_valu']['frac'])
+    print(r['config']['models_per_gpu'], '%.3e evals/s'%r['value'], 'step %.2f ms'%r['ms_per_step'], 'swd %.2f ms rf %.2f ms'%(r['kernels_ms']['swd_kernel'], r['kernels_ms']['rf_kernel']), 'fp64 frac %.3f'%r['roofline']['frac'])
 PY
