@@ -17,6 +17,12 @@ Bounds derived from that criterion:
                        = 2e-4 U/c, with U <= c for normal dispersion; the fp32 evaluation of the
                        cancelling denominator adds ~1e-5.
 
+(Two runs each stop somewhere inside their own final bracket around the same root, so in the worst case
+two results are the sum of two brackets apart: 2e-6 c and 4e-4 U.  A random campaign over 3.1 M searches
+incl. higher modes, earth flattening, water layers and irregular periods -- tests/scenarios/kernel_fuzz.py,
+profiles/r02_kernel_fuzz.txt -- saw at most 1.7e-6 and 6.6e-4; fundamental mode on a flat earth, which is
+what the test sets below are: 1.05e-6 and 2.1e-4.  All kernel forms agree with each other bit for bit.)
+
 Evidence that this is the reference's own reproducibility limit, not an implementation difference
 (profiles/r02_libm_selfdiff.txt, tests/scenarios/libm_selfdiff.py): the reference's native code
 run against ITSELF with glibc's non-FMA sin/cos/exp builds instead of the FMA ones differs on
