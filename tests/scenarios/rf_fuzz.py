@@ -1,0 +1,74 @@
+"""GPU-box campaign: random receiver-function configurations against the oracle.
+
+Random batch size, depth (1..40 layers, uniform or ragged), low-velocity zones, Gauss factor, slowness,
+transform length (64..4096), sampling rate, P / SV, fixed or model-derived rotation velocity.  Reports the
+largest deviation relative to the trace's scale; NaN patterns must be identical.
+
+    python tests/scenarios/rf_fuzz.py [seconds] [seed]  > gpurun_out/rf_fuzz.txt
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from bayhunter_amd.engine import ForwardEngine, RfSpec  # noqa: E402
+from bayhunter_amd.synthetic import draw_models  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+
+def main(seconds=180.0, seed=1):
+    rs = np.random.RandomState(seed)
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    t_end = time.time() + seconds
+    ncfg = nmod = 0
+    worst, where = 0.0, ''
+    while time.time() < t_end:
+        B = int(rs.choice([1, 5, 6, 7, 64, 300, 1000]))
+        lo = int(rs.randint(1, 25))
+        L = lo if rs.rand() < 0.5 else (lo, int(lo + rs.randint(0, 16)))
+        srt = rs.rand() < 0.5
+        deep = (L if isinstance(L, int) else L[1]) > 25
+        H, VP, VS, RHO, nl = draw_models(B, L, seed=int(rs.randint(1 << 30)), sorted_vs=srt,
+                                         **(dict(zmax=200.0, thickmin=0.05) if deep else {}))
+        fsamp = float(rs.choice([2.0, 5.0, 10.0, 20.0]))
+        nobs = int(rs.choice([20, 60, 100, 201, 400, 900, 1800]))
+        tshift = float(rs.choice([2.0, 5.0, 10.0]))
+        x = np.arange(nobs) / fsamp - tshift
+        gauss = float(rs.uniform(0.5, 3.0))
+        p = float(rs.uniform(3.0, 9.0))
+        wn = int(rs.rand() < 0.4)
+        nsv = None if rs.rand() < 0.6 else float(rs.uniform(2.5, 4.0))
+        eng = ForwardEngine(rf=[RfSpec('srf' if wn else 'prf', x, gauss, p, nsv)])
+        nsamp = int(eng.rf[0].nsamp)
+        if nsamp > 4096:
+            continue
+        out, _ = eng.run(H, VP, VS, RHO, nl)
+        out = out.cpu().numpy()
+        want = po.rf_batch(H, VP, VS, RHO, nl, p, gauss, nsamp, fsamp, tshift, nsv, wn, nout=nobs, nthreads=threads)
+        tag = 'B=%d L=%s %s nsamp=%d fs=%g a=%.2f p=%.2f wave=%d nsv=%s' % (B, L, 'sorted' if srt else 'lvz', nsamp, fsamp, gauss, p, wn, nsv)
+        if not np.array_equal(np.isfinite(out), np.isfinite(want)):
+            print('NaN PATTERN differs: ' + tag, flush=True)
+            return 1
+        fin = np.isfinite(want).all(axis=1)
+        if fin.any():
+            scale = np.maximum(1.0, np.abs(want[fin]).max(axis=1, keepdims=True))
+            d = float((np.abs(out[fin] - want[fin]) / scale).max())
+            if d > worst:
+                worst, where = d, tag
+            if d > 1e-10:
+                print('DEVIATION %.3e > 1e-10: %s' % (d, tag), flush=True)
+                return 1
+        ncfg += 1
+        nmod += B
+        if ncfg % 50 == 0:
+            print('%d configurations, %d models, worst deviation / scale %.2e (%s)' % (ncfg, nmod, worst, where), flush=True)
+    print('DONE: %d configurations, %d models: NaN patterns identical, worst deviation relative to the scale of a trace '
+          '%.2e at %s' % (ncfg, nmod, worst, where))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main(float(sys.argv[1]) if len(sys.argv) > 1 else 180.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
