@@ -63,7 +63,9 @@ BH_HD RfLayout rf_layout(int Lmax, int nsamp)
     RfLayout lo;
     int nfreq = nsamp / 2 + 1;
     lo.L = Lmax;
-    lo.off_par = 2 * nfreq;            // [9][L]: d, vp, vs, rho, 1/(pi qp), 1/(pi qs), 1/vp^2, 1/vs^2,
+    // the spectrum occupies elements 0 .. n/2 of the (swizzled, rf_swz) FFT buffer: element n/2 may
+    // land anywhere in its 16-element row, so the parameters start behind that row
+    lo.off_par = 2 * (nfreq + 15);     // [9][L]: d, vp, vs, rho, 1/(pi qp), 1/(pi qs), 1/vp^2, 1/vs^2,
                                        //         interface coefficients real?
     lo.off_coef = lo.off_par + 9 * Lmax; // [L][RF_COEF]: rd, td, ru, tu of interface i (above layer i)
     lo.off_sc = lo.off_coef + RF_COEF * Lmax; // 16 scalars

@@ -200,6 +200,13 @@ static int rf_hostsim_model(int nlay, const double *h, const double *vp, const d
     std::vector<cd> spec(P.nfreq);
     for (int j = 0; j < P.nfreq; j++) spec[j] = j < P.nact ? rf_phase3_task(S.data(), lo, P, nlay, j) : mk(0., 0.);
     double *X = S.data();
+    // layout invariant of the kernel: while phase 3 runs, spectrum stores (threads that are done) must
+    // not touch the parameter / coefficient region other threads still read
+    for (int j = 0; j < P.nfreq; j++)
+        if (2 * rf_swz(j) + 1 >= lo.off_par) {
+            for (int i = 0; i < nout; i++) rf[i] = std::nan("");
+            return -1;
+        }
     for (int j = 0; j < P.nfreq; j++) rf_xst(X, j, spec[j]);
     for (int i = nsamp / 2 + 1; i < nsamp; i++) rf_fft_hermitian(X, nsamp, i);
     for (int i = 0; i < nsamp; i++) rf_fft_bitrev_scale(X, nsamp, P.log2n, P.sc, i);

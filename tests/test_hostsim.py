@@ -106,6 +106,19 @@ def test_rf_workgroup_program(oracle, hostsim, wn):
             assert np.abs(a - r).max() <= 1e-12 * max(1.0, np.abs(a).max())
 
 
+@pytest.mark.parametrize('nsamp', [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_rf_every_transform_length(oracle, hostsim, nsamp):
+    """All power-of-two lengths: the swizzled FFT buffer (rf_swz) keeps the spectrum clear of the
+    parameter region during phase 3 (the replay checks that and returns NaN otherwise) and the
+    transform equals the reference's."""
+    H, VP, VS, RHO, nl = draw_models(3, (2, 12), seed=640 + nsamp, sorted_vs=False)
+    for b in range(3):
+        n = nl[b]
+        a = oracle.rf_model(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], 6.0, 1.3, nsamp, 10.0, 2.0, None, 0, nsamp // 2)
+        r = hostsim.rf(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], 6.0, 1.3, nsamp, 10.0, 2.0, None, 0, nsamp // 2)
+        assert np.all(np.isfinite(r)) and np.abs(a - r).max() <= 1e-12 * max(1.0, np.abs(a).max())
+
+
 def _ulp_err(got, x, fn):
     ref = fn(x.astype(np.longdouble))
     u = np.spacing(np.abs(ref.astype(np.float64)))
