@@ -145,17 +145,17 @@ def test_gpu_evaluate_batch_large_consistent_with_host(lib, g):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n', [5, 64, 130, 300, 1024])
-def test_gpu_gauss_quadratic_form_all_tile_shapes(lib, n):
+@pytest.mark.parametrize('n,B', [(5, 37), (64, 1), (130, 37), (201, 130), (208, 64), (209, 65), (300, 37), (1024, 37)])
+def test_gpu_gauss_quadratic_form_all_tile_shapes(lib, n, B):
     """bh_likelihood_batch straight through the C ABI for dense-Gaussian targets of every MFMA tile
-    variant (4/8/13/16 column tiles, multi-pass above 256 points), with and without the matrix-core
-    workspace, no err-flag columns, batch not a multiple of 16; against NumPy with an ASYMMETRIC
+    variant (4/8/13 column tiles, several passes above 208 points; four waves = 64 models per workgroup,
+    R^-1 staged through LDS in 16-row chunks), with and without the matrix-core workspace, no err-flag
+    columns, batches that are not a multiple of 16 or 64; against NumPy with an ASYMMETRIC
     'R^-1' (catches a transposed operand) ."""
     import ctypes as C
     import torch
     from bayhunter_amd import _lib
     rs = np.random.RandomState(n)
-    B = 37
     out = rs.normal(size=(B, n + 3))
     yobs = np.zeros(n + 3)
     yobs[3:] = rs.normal(size=n)
