@@ -85,6 +85,7 @@ BH_DEV double xsqrt(double x)
 #endif
 
 BH_DEV double dsign1(double x) { return copysign(1.0, x); }
+BH_DEV double bh_fmax(double a, double b) { return __builtin_fmax(a, b); }
 BH_DEV double dmin(double a, double b) { return a < b ? a : b; }
 BH_DEV double dmax(double a, double b) { return a > b ? a : b; }
 

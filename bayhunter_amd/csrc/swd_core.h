@@ -117,12 +117,9 @@ BH_DEV void swd_dunkin_apply(double e[5], const Dunkin &a)
     double ee3 = ((((0.0 + e1 * a.c13) + e2 * a.c23) + e3 * a.c33) + e4 * a.c43) + e5 * a.c53;
     double ee4 = ((((0.0 + e1 * a.c14) + e2 * a.c24) + e3 * a.c34) + e4 * a.c22) + e5 * a.c21;
     double ee5 = ((((0.0 + e1 * a.c15) + e2 * a.c14) + e3 * a.c35) + e4 * a.c12) + e5 * a.c11;
-    double t1 = 0.0;
-    if (fabs(ee1) > t1) t1 = fabs(ee1);
-    if (fabs(ee2) > t1) t1 = fabs(ee2);
-    if (fabs(ee3) > t1) t1 = fabs(ee3);
-    if (fabs(ee4) > t1) t1 = fabs(ee4);
-    if (fabs(ee5) > t1) t1 = fabs(ee5);
+    // t1 = max |ee_i| (normc's chain of `if (abs(ee_i) > t1) t1 = abs(ee_i)` from t1 = 0: a NaN entry is
+    // skipped there, and fmax returns its other argument for a NaN: same value in every case)
+    double t1 = bh_fmax(bh_fmax(bh_fmax(bh_fmax(bh_fmax(0.0, fabs(ee1)), fabs(ee2)), fabs(ee3)), fabs(ee4)), fabs(ee5));
     if (t1 < 1.e-40) t1 = 1.0;
     const Recip by_t1 = recip_of(t1);
     e[0] = qdiv(ee1, by_t1); e[1] = qdiv(ee2, by_t1); e[2] = qdiv(ee3, by_t1);
@@ -247,7 +244,7 @@ BH_DEV void swd_love_apply(double &e1, double &e2, const LoveLayer &o)
     double e10 = e1 * o.cosq + e2 * o.xmu * o.z;
     double e20 = xdiv(e1 * o.y, o.xmu) + e2 * o.cosq;
     double xnor = fabs(e10), ynor = fabs(e20);
-    if (ynor > xnor) xnor = ynor;
+    if (ynor > xnor) xnor = ynor;                     // (surfdisp96.f:760-763, as written: xnor = |e10| may be NaN)
     if (xnor < 1.e-40) xnor = 1.0;
     const Recip by_nor = recip_of(xnor);
     e1 = qdiv(e10, by_nor);
