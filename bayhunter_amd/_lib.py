@@ -13,8 +13,13 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
 SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip", "chains.cpp"]
 HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "swd_team.h", "rf_core.h", "rf_host.h", "kernels.h"]
+# -disable-machine-licm (device code only): the kernels are register-bound, and constants hoisted out
+# of the persistent loops (polynomial coefficients, masks) end up in VGPR pairs or spilled SGPRs and are
+# copied back at every use; rematerialised next to their use they are scalar moves.  swd_kernel 254 ->
+# 189 VGPRs, 451 -> 413 vector instructions per layer step, 55.2 -> 52.4 ms.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+               "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+               "-Xarch_device", "-mllvm=-disable-machine-licm"]
 
 BH_OK, BH_ERR_ARG, BH_ERR_HIP, BH_ERR_NO_DEVICE, BH_ERR_WORKSPACE = 0, 1, 2, 3, 4
 MAX_LAYERS, MAX_PERIODS, MAX_TARGETS = 100, 60, 16

@@ -22,12 +22,29 @@
 
 namespace bh {
 
+// bh_fma_k(a, b, K) = fma(a, b, K) for a compile-time constant K: a Horner step.  The compiler keeps
+// polynomial coefficients in VGPR pairs and, the kernels being at their register limit, copies each
+// into the accumulator before a two-address v_fmac_f64 (a v_mov_b64 per step: 50 of the ~450 vector
+// instructions of a layer step of swd_kernel).  The three-address form with the coefficient as a scalar
+// operand needs neither the copy nor the VGPRs.  K MUST be a constant (an "s" operand is read from one
+// lane).  (-DBH_NO_FMA_K: the plain builtin, for A/B measurements.)
 #if defined(BH_HOSTSIM)
 BH_DEV double bh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+BH_DEV double bh_fma_k(double a, double b, double k) { return __builtin_fma(a, b, k); }
 BH_DEV double bh_rint(double x) { return __builtin_rint(x); }
 BH_DEV double bh_ldexp(double x, int k) { return __builtin_ldexp(x, k); }
 #else
 BH_DEV double bh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#if defined(BH_NO_FMA_K)
+BH_DEV double bh_fma_k(double a, double b, double k) { return __builtin_fma(a, b, k); }
+#else
+BH_DEV double bh_fma_k(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+#endif
 BH_DEV double bh_rint(double x) { return __builtin_rint(x); }
 BH_DEV double bh_ldexp(double x, int k) { return __builtin_amdgcn_ldexp(x, k); }
 #endif
@@ -82,14 +99,14 @@ BH_DEV void bh_sincos(double x, double *sn, double *cs)
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     double v = z * y0;
-    double rs = bh_fma(z, bh_fma(z, bh_fma(z, bh_fma(z, S6, S5), S4), S3), S2);
+    double rs = bh_fma_k(z, bh_fma_k(z, bh_fma_k(z, bh_fma(z, S6, S5), S4), S3), S2);
     double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
     // __kernel_cos(y0, y1)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     double ww = z * z;
-    double rc = z * bh_fma(z, bh_fma(z, C3, C2), C1) + (ww * ww) * bh_fma(z, bh_fma(z, C6, C5), C4);
+    double rc = z * bh_fma_k(z, bh_fma(z, C3, C2), C1) + (ww * ww) * bh_fma_k(z, bh_fma(z, C6, C5), C4);
     double hz = 0.5 * z;
     double w1 = 1.0 - hz;
     double c = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
@@ -113,16 +130,16 @@ BH_DEV double bh_exp(double x)
     r = bh_fma(-k, LN2_LO, r);
     // exp(r) on |r| <= ln2/2: Taylor to degree 13 (truncation 4e-18)
     double p = 1.6059043836821613e-10;                  // 1/13!
-    p = bh_fma(p, r, 2.08767569878681e-09);             // 1/12!
-    p = bh_fma(p, r, 2.505210838544172e-08);            // 1/11!
-    p = bh_fma(p, r, 2.755731922398589e-07);            // 1/10!
-    p = bh_fma(p, r, 2.7557319223985893e-06);           // 1/9!
-    p = bh_fma(p, r, 2.48015873015873e-05);             // 1/8!
-    p = bh_fma(p, r, 1.984126984126984e-04);            // 1/7!
-    p = bh_fma(p, r, 1.3888888888888889e-03);           // 1/6!
-    p = bh_fma(p, r, 8.333333333333333e-03);            // 1/5!
-    p = bh_fma(p, r, 4.1666666666666664e-02);           // 1/4!
-    p = bh_fma(p, r, 1.6666666666666666e-01);           // 1/3!
+    p = bh_fma_k(p, r, 2.08767569878681e-09);             // 1/12!
+    p = bh_fma_k(p, r, 2.505210838544172e-08);            // 1/11!
+    p = bh_fma_k(p, r, 2.755731922398589e-07);            // 1/10!
+    p = bh_fma_k(p, r, 2.7557319223985893e-06);           // 1/9!
+    p = bh_fma_k(p, r, 2.48015873015873e-05);             // 1/8!
+    p = bh_fma_k(p, r, 1.984126984126984e-04);            // 1/7!
+    p = bh_fma_k(p, r, 1.3888888888888889e-03);           // 1/6!
+    p = bh_fma_k(p, r, 8.333333333333333e-03);            // 1/5!
+    p = bh_fma_k(p, r, 4.1666666666666664e-02);           // 1/4!
+    p = bh_fma_k(p, r, 1.6666666666666666e-01);           // 1/3!
     p = bh_fma(p, r, 0.5);
     p = bh_fma(p, r, 1.0);
     p = bh_fma(p, r, 1.0);
@@ -141,16 +158,16 @@ BH_DEV double bh_exp_bounded(double x)
     double r = bh_fma(-k, LN2_HI, x);
     r = bh_fma(-k, LN2_LO, r);
     double p = 1.6059043836821613e-10;
-    p = bh_fma(p, r, 2.08767569878681e-09);
-    p = bh_fma(p, r, 2.505210838544172e-08);
-    p = bh_fma(p, r, 2.755731922398589e-07);
-    p = bh_fma(p, r, 2.7557319223985893e-06);
-    p = bh_fma(p, r, 2.48015873015873e-05);
-    p = bh_fma(p, r, 1.984126984126984e-04);
-    p = bh_fma(p, r, 1.3888888888888889e-03);
-    p = bh_fma(p, r, 8.333333333333333e-03);
-    p = bh_fma(p, r, 4.1666666666666664e-02);
-    p = bh_fma(p, r, 1.6666666666666666e-01);
+    p = bh_fma_k(p, r, 2.08767569878681e-09);
+    p = bh_fma_k(p, r, 2.505210838544172e-08);
+    p = bh_fma_k(p, r, 2.755731922398589e-07);
+    p = bh_fma_k(p, r, 2.7557319223985893e-06);
+    p = bh_fma_k(p, r, 2.48015873015873e-05);
+    p = bh_fma_k(p, r, 1.984126984126984e-04);
+    p = bh_fma_k(p, r, 1.3888888888888889e-03);
+    p = bh_fma_k(p, r, 8.333333333333333e-03);
+    p = bh_fma_k(p, r, 4.1666666666666664e-02);
+    p = bh_fma_k(p, r, 1.6666666666666666e-01);
     p = bh_fma(p, r, 0.5);
     p = bh_fma(p, r, 1.0);
     p = bh_fma(p, r, 1.0);

@@ -144,7 +144,10 @@ struct QueueSrc {
 };
 
 // 2 waves per SIMD: the search state + one Dunkin layer need ~250 VGPRs; pin the allocator there
-__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_kernel(SwdArgs A)
+#ifndef BH_SWD_WAVES
+#define BH_SWD_WAVES 2            // waves per SIMD the register budget of swd_kernel is set for
+#endif
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(BH_SWD_WAVES, BH_SWD_WAVES))) void swd_kernel(SwdArgs A)
 {
     extern __shared__ float lds[];
     const int t = blockIdx.y;
