@@ -378,7 +378,7 @@ __device__ __forceinline__ T *uni(T *p)
 }
 struct TeamwVals {
     double mc, mom, dl;                   // slot (lane & 63) of the round and its value
-    int nt, scan0, stride, nscan;
+    int nt;
 #if defined(BH_TEAM_PROFILE)
     unsigned long long *tp, *t0;
     __device__ __forceinline__ void probe(int i) const { const unsigned long long t = clock64(); tp[i] += t - *t0; *t0 = t; }
@@ -394,11 +394,12 @@ struct TeamwVals {
     }
     __device__ __forceinline__ double del(int j) const { return readlane_d(dl, j); }
     __device__ __forceinline__ double c(int j) const { return readlane_d(mc, j); }
-    // scan trials i, i+1, ... in a row that are valid and whose value has sign bit `neg`
-    __device__ __forceinline__ int run(int i, bool neg) const
+    // slots first, first + stride, ... (at most count) in a row that are valid and whose value has sign
+    // bit `neg`
+    __device__ __forceinline__ int run(int first, int stride, int count, bool neg) const
     {
         const bool same = (mc == mc) && ((__double2hiint(dl) < 0) == neg) && (int)(threadIdx.x & 63) < nt;
-        unsigned long long m = __ballot(same) >> (scan0 + i * stride);
+        unsigned long long m = __ballot(same) >> first;
         int n;
         if (stride == 2) {
             const unsigned long long stop = ~m & 0x5555555555555555ull;     // scan slots are the even ones
@@ -407,7 +408,7 @@ struct TeamwVals {
             const unsigned long long stop = ~m;
             n = stop ? __ffsll((long long)stop) - 1 : 64;
         }
-        return n < nscan - i ? n : nscan - i;
+        return n < count ? n : count;
     }
 };
 
@@ -553,9 +554,9 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         __syncthreads();
         BH_TP(3);
 #if defined(BH_TEAM_PROFILE)
-        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, R.scan0, R.stride, R.nscan, tp_, &tp_t0_};
+        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, tp_, &tp_t0_};
 #else
-        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, R.scan0, R.stride, R.nscan};
+        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt};
 #endif
         const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
         BH_TP(4);

@@ -209,6 +209,9 @@ BH_DEV int swd_team_consume(SwdState &S, Nev &nv, int nt, const double *trials, 
 //     lane's column is one 48-byte run (kernels.hip).
 // Trials of a round are numbered 0..nt-1; trial j has its own (c, omega).
 enum { SWD_TEAMW_NT = 32 };       // max trials per round
+#ifndef SWD_TEAMW_MIDROOM
+#define SWD_TEAMW_MIDROOM 24   // scan slots from which on the cell midpoints ride along (replay: 16 and 24 within 1 %)
+#endif
 
 enum { SWD_MAT = 30 };            // doubles per stored layer matrix: 5 columns x 6 (5 used, 16-byte aligned)
 
@@ -217,24 +220,38 @@ enum { SWD_MAT = 30 };            // doubles per stored layer matrix: 5 columns 
 //   bracketing (ST_A / ST_B)   the scan continues on the grid: scan trial i = base + (i+1) dc by
 //                              repeated addition (surfdisp96.f:448-470), assuming the upward
 //                              direction getsol takes for normal dispersion
-//   refinement (ST_TOP / MID)  (1) the midpoints of the bracket this trial leaves: the next point if
-//                              the next step is a bisection (`half`, :620-640) -- 2 candidates, and the
-//                              4 of the step after it (about half of nevill's steps are bisections);
-//                              (2) the search that follows if this trial is the root: its entry
-//                              evaluation at c - 1.5 dc with the next period's omega (or the second
-//                              solve of a group-velocity pair, :268-271,:282-294) and its scan
+//   refinement (ST_TOP / MID)  (1) the bisection tree below the pending trial.  Nine refinement steps
+//                              in ten are bisections (`half`, :620-640: forced while the end values of
+//                              the bracket differ by > 100x, and 0.005 -> 1e-6 c takes 11 of them), and
+//                              a bisection point is known before the value that selects it: the
+//                              midpoint of one of the two sub-brackets the pending trial can leave.  A
+//                              tree of depth D -- 2, 4, 8, ... candidates per level, 2^(D+1)-2 slots --
+//                              lets a round consume D+1 values.  D is bounded by the slots and by the
+//                              number of halvings left before the stopping test |c1-c2| <= 1e-6 c1
+//                              (:614) fires, which the bracket width predicts.
+//                              (2) once the tree reaches that last halving its leaves are the possible
+//                              roots: behind each (at most two) comes the search that follows -- its
+//                              entry evaluation at c - 1.5 dc with the next period's omega (or the
+//                              second solve of a group-velocity pair, :268-271,:282-294) and its scan
 //   with >= 16 slots to spare  the midpoint of every scan cell: nevill's first point (:583) if the
 //                              sign change lies in that cell
 // The plan is a pure function of the (wave-uniform) state: swd_teamw_round lays the slots out,
 // swd_teamw_trial gives slot j's (c, omega) -- on the device lane j computes its own.  A slot whose
-// scan has left the search bounds is NaN (never matched).
-struct TeamwRound {
-    int nt;                       // slots in use
-    int nhalf;                    // 0, 2 or 6 bisection candidates in slots 1 .. nhalf
-    int entry;                    // slot of a successor search's entry evaluation, or -1
+// scan has left the search bounds is NaN (never matched).  Every prediction here may be wrong (a
+// Neville step instead of a bisection, a reversed scan, no root): values are consumed by matching
+// (omega, c), so a wrong prediction costs idle lanes and nothing else.
+struct TeamwScan {                // an entry evaluation (optional) and the scan that steps away from it
+    int entry;                    // slot of the entry evaluation (c = base), or -1
     int scan0, stride, nscan;     // scan trial i in slot scan0 + i*stride, i < nscan (stride 2: cell
                                   // midpoints in between)
     double base, oms;             // the point the scan steps away from, omega of the scan
+};
+struct TeamwRound {
+    int nt;                       // slots in use
+    int nhalf;                    // bisection candidates in slots 1 .. nhalf (0, 2, 6, 14 or 30): the
+                                  // tree in level order, left (c1 side) to right
+    int ngrp;                     // scan groups in use (0..2); g1 follows g0
+    TeamwScan g0, g1;
 };
 
 // omega of the search that follows the current one, kept across the rounds of a search (k, pass)
@@ -242,65 +259,104 @@ struct TeamwNext {
     int k, pass;
     double oms;
 };
+
+// lays one scan group out in slots [first, first + room): entry (if has_entry) + scan
+BH_DEV int swd_teamw_scan_layout(TeamwScan &g, int first, int room, bool has_entry, bool scan_ok)
+{
+    g.entry = -1; g.scan0 = first; g.stride = 1; g.nscan = 0;
+    if (room <= 0) return first;
+    if (has_entry) { g.entry = first; g.scan0 = first + 1; room--; }
+    if (!scan_ok || room <= 0) return g.scan0;
+    g.stride = room >= SWD_TEAMW_MIDROOM ? 2 : 1;
+    g.nscan = (room + g.stride - 1) / g.stride;     // stride 2 and odd room: the last cell has no midpoint
+    return g.scan0 + room;
+}
+
 BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, const double *BH_RESTRICT per,
                                   int cap, TeamwNext &nx)
 {
     const double dc = (double)0.005f;
     TeamwRound R;
-    R.nt = 1; R.nhalf = 0; R.entry = -1; R.scan0 = 1; R.stride = 1; R.nscan = 0;
-    R.base = S.ceval; R.oms = S.omega;
+    R.nt = 1; R.nhalf = 0; R.ngrp = 0;
+    R.g0.entry = -1; R.g0.scan0 = 1; R.g0.stride = 1; R.g0.nscan = 0; R.g0.base = S.ceval; R.g0.oms = S.omega;
+    R.g1 = R.g0;
     if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
     if (cap <= 1) return R;
-    double clows;
-    bool scan_ok;
     if (S.st == SWD_ST_A) {
-        clows = S.clow;
-        scan_ok = true;
-    } else if (S.st == SWD_ST_B) {
-        // slot 0 is itself a scan point: the step from S.c1
-        clows = S.clow;
-        R.base = S.c1;
-        R.scan0 = 0;
-        scan_ok = S.idir > 0 && S.c1 + dc == S.ceval;
-    } else {
-        if (cap >= 4) R.nhalf = cap >= 12 ? 6 : 2;
-        R.nt = 1 + R.nhalf;
-        R.scan0 = R.nt + 1;
-        if (R.nt >= cap || tg.mode != 1 || S.iq != 1 || S.ceval > (double)S.betmx) return R;
-        // which search follows if this trial is the root?  (mirror of swd_driver; only the plain
-        // case -- fundamental mode, no workspace -- is predicted)
-        const double TWOPI = 2.0 * 3.141592653589793, one = 1.0e-2, onea = 1.5;
-        const float h = 0.005f;
-        const bool fresh = nx.k != S.k || nx.pass != S.pass;
-        if (tg.igr > 0 && S.pass == 0) {            // second solve of the pair, surfdisp96.f:282-294
-            if (fresh) nx.oms = TWOPI / (double)S.t1b;
-            R.base = S.ceval - onea * dc;
-            clows = 0.0 + one * dc;
-        } else {                                    // next period, surfdisp96.f:231-239,268-271
-            const int k2 = S.k + 1;
-            if (k2 > tg.nper || k2 >= S.ift) return R;
-            if (fresh) {
-                double t1 = per[k2 - 1];
-                if (tg.igr > 0) t1 = (double)(float)(t1 / (double)(1.f + h));
-                nx.oms = TWOPI / t1;
-            }
-            R.base = ((S.pass == 0) ? S.ceval : S.ck) - onea * dc;
-            clows = S.cc;
-        }
-        nx.k = S.k; nx.pass = S.pass;
-        R.oms = nx.oms;
-        R.entry = R.nt++;
-        scan_ok = true;
+        // the scan is only laid out in its plain form: upwards, never turned around at clow
+        // (swd_bracket_next resets c1 to clow when c1 + dc <= clow)
+        R.ngrp = 1;
+        R.nt = swd_teamw_scan_layout(R.g0, 1, cap - 1, false, R.g0.base + dc > S.clow);
+        return R;
     }
-    // the scan is only laid out in its plain form: upwards, never turned around at clow
-    // (swd_bracket_next resets c1 to clow when c1 + dc <= clow)
-    if (!scan_ok || !(R.base + dc > clows)) { if (R.scan0 == 0) R.scan0 = 1; return R; }
-    const int room = cap - (R.scan0 == 0 ? 0 : R.nt);
-    if (room <= 0) return R;
-    R.stride = room >= 16 ? 2 : 1;
-    R.nscan = (room + R.stride - 1) / R.stride;     // stride 2 and odd room: the last cell has no midpoint
-    R.nt = (R.scan0 == 0 ? 0 : R.nt) + room;
+    if (S.st == SWD_ST_B) {
+        // slot 0 is itself a scan point: the step from S.c1
+        R.g0.base = S.c1;
+        if (S.idir > 0 && S.c1 + dc == S.ceval && R.g0.base + dc > S.clow) {
+            R.ngrp = 1;
+            R.nt = swd_teamw_scan_layout(R.g0, 0, cap, false, true);
+        }
+        return R;
+    }
+    // refinement.  Evaluations left if every step from here on is a bisection: the pending one, plus
+    // one per halving until the bracket is narrower than the stopping tolerance.
+    int left = 1;
+    {
+        const double wa = fabs(S.ceval - S.c1), wb = fabs(S.c2 - S.ceval), tol = 1.e-6 * fabs(S.ceval);
+        double w = wa > wb ? wa : wb;
+        while (w > tol && left < 6) { w *= 0.5; left++; }
+    }
+    int depth = 0;
+    while (depth < left - 1 && (4 << depth) - 1 <= cap) depth++;
+    R.nhalf = (2 << depth) - 2;
+    R.nt = 1 + R.nhalf;
+    // the search that follows, behind the leaves if they are the last evaluations of this one (mirror
+    // of swd_driver; only the plain case -- fundamental mode, no workspace -- is predicted)
+    if (depth != left - 1 || depth > 1 || R.nt >= cap || tg.mode != 1 || S.iq != 1 || S.ceval > (double)S.betmx)
+        return R;
+    const double TWOPI = 2.0 * 3.141592653589793, one = 1.0e-2, onea = 1.5;
+    const float h = 0.005f;
+    const bool fresh = nx.k != S.k || nx.pass != S.pass;
+    double clows;
+    bool per_leaf = true;                           // the start of the next search depends on this root
+    if (tg.igr > 0 && S.pass == 0) {                // second solve of the pair, surfdisp96.f:282-294
+        if (fresh) nx.oms = TWOPI / (double)S.t1b;
+        clows = 0.0 + one * dc;
+    } else {                                        // next period, surfdisp96.f:231-239,268-271
+        const int k2 = S.k + 1;
+        if (k2 > tg.nper || k2 >= S.ift) return R;
+        if (fresh) {
+            double t1 = per[k2 - 1];
+            if (tg.igr > 0) t1 = (double)(float)(t1 / (double)(1.f + h));
+            nx.oms = TWOPI / t1;
+        }
+        per_leaf = S.pass == 0;                     // (pass 1: it starts from c(k), the first root)
+        clows = S.cc;
+    }
+    nx.k = S.k; nx.pass = S.pass;
+    R.g0.oms = R.g1.oms = nx.oms;
+    const int room = cap - R.nt;
+    if (depth == 0 || !per_leaf) {
+        R.g0.base = ((S.pass == 0) ? S.ceval : S.ck) - onea * dc;
+        R.ngrp = 1;
+        R.nt = swd_teamw_scan_layout(R.g0, R.nt, room, true, R.g0.base + dc > clows);
+    } else {
+        // two leaves: the midpoints of the sub-brackets (slots 1 and 2)
+        const int r0 = (room + 1) / 2;
+        R.g0.base = 0.5 * (S.c1 + S.ceval) - onea * dc;
+        R.g1.base = 0.5 * (S.ceval + S.c2) - onea * dc;
+        R.ngrp = 2;
+        R.nt = swd_teamw_scan_layout(R.g0, R.nt, r0, true, R.g0.base + dc > clows);
+        R.nt = swd_teamw_scan_layout(R.g1, R.nt, room - r0, true, R.g1.base + dc > clows);
+        if (R.g1.entry < 0) R.ngrp = 1;
+    }
     return R;
+}
+
+// the scan group slot j (> nhalf) belongs to
+BH_DEV const TeamwScan &swd_teamw_group(const TeamwRound &R, int j)
+{
+    return (R.ngrp > 1 && j >= R.g1.entry) ? R.g1 : R.g0;
 }
 
 // Slot j of the round: (c, omega).  NaN marks a scan slot beyond the search bounds.
@@ -310,21 +366,30 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
     *c = S.ceval; *om = S.omega;
     if (j <= 0) return;
     if (j <= R.nhalf) {
-        const double ha = 0.5 * (S.c1 + S.ceval), hb = 0.5 * (S.ceval + S.c2);
-        const double lo = j == 3 ? S.c1 : j == 4 ? ha : j == 5 ? S.ceval : hb;
-        const double hi = j == 3 ? ha : j == 4 ? S.ceval : j == 5 ? hb : S.c2;
-        *c = j == 1 ? ha : j == 2 ? hb : 0.5 * (lo + hi);
+        // node j of the bisection tree in level order: level l = floor(log2(j+1)), position p in the
+        // level; walk down from the pending trial, a bit of p per level (0: the value there has the
+        // sign of del2 -> c2 = c3; 1: c1 = c3), taking midpoints exactly like nevill (:583,:661)
+        int l = 1;
+        while ((2 << l) - 1 <= j) l++;
+        const int pth = j + 1 - (1 << l);
+        double lo = S.c1, mid = S.ceval, hi = S.c2;
+        for (int b = l - 1; b >= 0; b--) {
+            if ((pth >> b) & 1) lo = mid; else hi = mid;
+            mid = 0.5 * (lo + hi);
+        }
+        *c = mid;
         return;
     }
-    *om = R.oms;
-    if (j == R.entry) { *c = R.base; return; }
-    const int q = j - R.scan0;
-    const int i = R.stride == 2 ? q >> 1 : q;        // scan cell
-    const bool mid = R.stride == 2 && (q & 1);
+    const TeamwScan &g = swd_teamw_group(R, j);
+    *om = g.oms;
+    if (j == g.entry) { *c = g.base; return; }
+    const int q = j - g.scan0;
+    const int i = g.stride == 2 ? q >> 1 : q;        // scan cell
+    const bool mid = g.stride == 2 && (q & 1);
     // base_0 = base, base_{n+1} = c_n = base_n + dc by repeated addition.  The scan stops at the first
     // base outside [cc, cfail) (swd_control: "c1 < cm or c1 >= betmx + dc -> no root"); the bases
     // increase, so it is enough to look at the first and at this cell's
-    double b = R.base, cn = R.base + dc;
+    double b = g.base, cn = g.base + dc;
     int n = i;
     for (; n >= 4; n -= 4) {
         const double c1 = cn + dc, c2 = c1 + dc, c3 = c2 + dc;
@@ -340,7 +405,7 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
         b = cn;
         cn = b + dc;
     }
-    const bool ok = !(R.base < S.cc) && !(b >= S.cfail);
+    const bool ok = !(g.base < S.cc) && !(b >= S.cfail);
     *c = ok ? (mid ? 0.5 * (b + cn) : cn) : __builtin_nan("");
 }
 
@@ -419,8 +484,9 @@ BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, 
 // a task boundary (next model) ends the round.
 //   vals   `int find(double om, double c)`: slot computed at exactly that point, or -1;
 //          `double del(int j)`, `double c(int j)`: value and velocity of slot j;
-//          `int run(int i, bool neg)`: how many of the scan trials i, i+1, ... (valid ones, in a
-//          row) have a value whose sign bit equals `neg`;
+//          `int run(int first, int stride, int count, bool neg)`: how many of the slots first,
+//          first + stride, ... (at most count) in a row are valid scan trials whose value has sign
+//          bit `neg`;
 //          `probe(int)`, `count(int, int)`: cycle probes of the diagnostic build, else empty.
 // Scan trials without a sign change are the bulk of all evaluations (two thirds) and
 // each costs a pass through swd_control although all it does is "c1 = c2, del1 = del2, next grid
@@ -438,15 +504,16 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
         const int j = used == 0 ? 0 : vals.find(S.omega, S.ceval);
         vals.probe(4);
         if (j < 0) break;
-        if (S.st == SWD_ST_B && S.idir > 0 && R.nscan > 0 && j >= R.scan0) {
-            const int q = j - R.scan0, i = q / R.stride;
-            if (q == i * R.stride && i < R.nscan) {
-                int m = vals.run(i, dsign1(S.del1) < 0.0);
+        if (S.st == SWD_ST_B && S.idir > 0 && R.ngrp > 0 && (R.nhalf == 0 || j > R.nhalf)) {
+            const TeamwScan &g = swd_teamw_group(R, j);
+            const int q = j - g.scan0, i = q / g.stride;
+            if (q >= 0 && q == i * g.stride && i < g.nscan) {
+                int m = vals.run(j, g.stride, g.nscan - i, dsign1(S.del1) < 0.0);
                 if (m > SWD_MAX_BRACKET_STEPS - S.nbrk) m = 0;          // (the hard step cap: one by one)
                 if (m > 0) {
                     // m steps of label 1000 without a sign change.  Every base of the run but the
                     // last lies inside the bounds (else the following slots would be NaN).
-                    const int last = R.scan0 + (i + m - 1) * R.stride;
+                    const int last = j + (m - 1) * g.stride;
                     S.del2 = vals.del(last);
                     S.c1 = vals.c(last);
                     S.del1 = S.del2;

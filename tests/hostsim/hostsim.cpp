@@ -116,11 +116,11 @@ struct ArrayVals {
     double c(int j) const { return tc[j]; }
     void probe(int) const {}
     void count(int, int) const {}
-    int run(int i, bool neg) const
+    int run(int first, int stride, int count, bool neg) const
     {
         int m = 0;
-        for (; i + m < R->nscan; m++) {
-            const int j = R->scan0 + (i + m) * R->stride;
+        for (; m < count; m++) {
+            const int j = first + m * stride;
             if (j >= R->nt || tc[j] != tc[j] || std::signbit(dl[j]) != neg) break;
         }
         return m;
@@ -159,10 +159,16 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         for (int j = 0; j < nt; j++) bh::swd_teamw_trial(R, S, j, &tc[j], &tom[j]);
         auto same = [](double a, double b) { return a == b || (a != a && b != b); };
         if (!same(tc[0], S.ceval) || !same(tom[0], S.omega)) return -101;
-        for (int i = 0; i + 1 < R.nscan; i++) {           // scan trials: consecutive grid points
-            const int j0 = R.scan0 + i * R.stride, j1 = j0 + R.stride;
-            if (j1 < nt && tc[j1] == tc[j1] && tc[j1] != tc[j0] + (double)0.005f) return -102;
+        for (int gi = 0; gi < R.ngrp; gi++) {             // scan trials: consecutive grid points
+            const bh::TeamwScan &g = gi ? R.g1 : R.g0;
+            if (g.entry >= 0 && (g.entry <= R.nhalf || g.entry >= nt || tc[g.entry] != g.base)) return -103;
+            for (int i = 0; i + 1 < g.nscan; i++) {
+                const int j0 = g.scan0 + i * g.stride, j1 = j0 + g.stride;
+                if (j0 <= R.nhalf - (R.nhalf == 0) || j1 >= nt + g.stride) return -104;
+                if (j1 < nt && tc[j1] == tc[j1] && tc[j1] != tc[j0] + (double)0.005f) return -102;
+            }
         }
+        if (R.ngrp > 1 && (R.g0.scan0 + R.g0.nscan * R.g0.stride > R.g1.entry + (R.g0.stride - 1))) return -105;
         for (int j = 0; j < nt; j++) {
             if (tc[j] != tc[j]) { dl[j] = 0.0; continue; }                    // NaN slot: not evaluated
             for (int rr = 0; rr < nlm; rr++)
