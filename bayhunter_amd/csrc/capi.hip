@@ -278,7 +278,7 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     // Which kernel: each form k has a latency lat_k (one search, chip mostly idle) and a saturation
     // rate thr_k (searches per ms with every SIMD busy); a call with s searches costs about
     // max(lat_k, s / thr_k).  Table measured on MI355X (256 CUs) for 21 periods, Rayleigh phase
-    // (profiles/r02_team_widths.txt; relative order is what matters), by deepest model of the batch;
+    // (profiles/r02_team_widths.txt, fitted by tools/fit_forms.py; relative order is what matters), by deepest model of the batch;
     // thr scales with the CU count.  Wide teams (64 W lanes, speculation across root searches) win up
     // to a few thousand searches, 8-lane teams in the ten-thousands, the lane kernel beyond.
     // bh_swd_set_kernel overrides; BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
@@ -286,14 +286,14 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     const long cus = resident > 0 ? resident / 8 : 256;
     struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
     static const Form forms[8] = {
-        {0,   {4.6, 6.8, 11.5, 16.0, 31.0},  {19500, 12850, 7280, 5020, 3250}},     // lane kernel
-        {8,   {2.7, 3.9, 6.8, 8.0, 14.0},    {4830, 3127, 1870, 1196, 640}},
-        {16,  {2.15, 2.9, 5.7, 7.0, 12.5},   {2980, 2167, 1274, 993, 770}},
-        {32,  {1.7, 2.2, 3.25, 4.7, 11.4},   {2050, 1520, 1014, 682, 595}},
-        {64,  {0.86, 0.88, 1.3, 1.77, 4.0},  {2240, 2000, 1290, 922, 760}},
-        {128, {0.75, 0.79, 1.0, 1.45, 2.4},  {1200, 1145, 840, 580, 470}},
-        {256, {0.77, 0.83, 0.95, 1.2, 2.0},  {650, 605, 490, 393, 313}},
-        {512, {0.89, 0.95, 1.15, 1.35, 2.05}, {330, 295, 234, 201, 168}},
+        {0,   {4.47, 6.29, 10.9, 15.6, 31.7}, {24638, 15294, 8131, 5540, 3382}},    // lane kernel
+        {8,   {2.67, 3.5, 6.07, 7.01, 12.5},  {5990, 4045, 2357, 1590, 750}},
+        {16,  {2.12, 2.69, 4.95, 6.03, 10.6}, {3715, 2695, 1472, 1154, 951}},
+        {32,  {1.68, 1.93, 2.86, 4.0, 9.07},  {2398, 1895, 1262, 860, 675}},
+        {64,  {0.69, 0.68, 1.05, 1.67, 3.81}, {3022, 2736, 1755, 1082, 873}},
+        {128, {0.6, 0.58, 0.91, 1.17, 2.23},  {1558, 1340, 865, 644, 447}},
+        {256, {0.61, 0.59, 0.78, 0.96, 1.62}, {857, 774, 594, 471, 357}},
+        {512, {0.71, 0.7, 0.9, 1.02, 1.71},   {418, 378, 303, 263, 194}},
     };
     const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
     bool team = false;

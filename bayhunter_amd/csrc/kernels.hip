@@ -261,12 +261,12 @@ struct TeamSrc {
 // phase of the 64-lane team loop, summed over all searches; read back with bh_debug_team_profile.
 #if defined(BH_TEAM_PROFILE)
 __device__ unsigned long long g_team_prof[16];
-#define BH_TP_DECL unsigned long long tp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_t0_ = clock64(), tp_t1_
+#define BH_TP_DECL unsigned long long tp_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_t0_ = clock64(), tp_t1_
 #define BH_TP(i) (tp_t1_ = clock64(), tp_[i] += tp_t1_ - tp_t0_, tp_t0_ = tp_t1_)
 #define BH_TP_COUNT(i, n) (tp_[i] += (n))
 #define BH_TP_FLUSH(rounds)                                                                  \
     if (threadIdx.x == 0) {                                                                  \
-        for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_team_prof[i_], tp_[i_]);                \
+        for (int i_ = 0; i_ < 14; i_++) atomicAdd(&g_team_prof[i_], tp_[i_]);                \
         atomicAdd(&g_team_prof[14], (unsigned long long)(rounds));                           \
         atomicAdd(&g_team_prof[15], 1ull);                                                   \
     }
@@ -376,9 +376,15 @@ __device__ __forceinline__ T *uni(T *p)
     return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                  (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
+struct LdsDel {                    // period-equation values of the round's slots
+    const double *d;
+    __device__ __forceinline__ double operator()(int j) const { return d[j]; }
+};
 struct TeamwVals {
     double mc, mom, dl;                   // slot (lane & 63) of the round and its value
     int nt;
+    TeamwNode nd;                         // tree node (lane & 63): arrival bracket (swd_teamw_node)
+    unsigned long long left, right;       // nodes whose decision is SWD_GO_LEFT / SWD_GO_RIGHT
 #if defined(BH_TEAM_PROFILE)
     unsigned long long *tp, *t0;
     __device__ __forceinline__ void probe(int i) const { const unsigned long long t = clock64(); tp[i] += t - *t0; *t0 = t; }
@@ -394,6 +400,18 @@ struct TeamwVals {
     }
     __device__ __forceinline__ double del(int j) const { return readlane_d(dl, j); }
     __device__ __forceinline__ double c(int j) const { return readlane_d(mc, j); }
+    __device__ __forceinline__ int go(const SwdState &, int j) const
+    {
+        return ((right >> j) & 1) ? SWD_GO_RIGHT : ((left >> j) & 1) ? SWD_GO_LEFT : SWD_GO_STOP;
+    }
+    __device__ __forceinline__ TeamwNode node(const SwdState &, int j) const
+    {
+        TeamwNode a;
+        a.go = SWD_GO_STOP;
+        a.c1 = readlane_d(nd.c1, j); a.d1 = readlane_d(nd.d1, j);
+        a.c2 = readlane_d(nd.c2, j); a.d2 = readlane_d(nd.d2, j);
+        return a;
+    }
     // slots first, first + stride, ... (at most count) in a row that are valid and whose value has sign
     // bit `neg`
     __device__ __forceinline__ int run(int first, int stride, int count, bool neg) const
@@ -553,10 +571,21 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         }
         __syncthreads();
         BH_TP(3);
+        // refinement round: lane j evaluates node j of the bisection tree (what the search does when it
+        // arrives there), the consuming loop then follows the decisions
+        TeamwNode nd;
+        nd.go = SWD_GO_STOP; nd.c1 = nd.d1 = nd.c2 = nd.d2 = 0.0;
+        unsigned long long goL = 0, goR = 0;
+        if (R.nhalf > 0) {
+            const bool innode = wl <= R.nhalf;
+            nd = swd_teamw_node(S, LdsDel{dels}, innode ? wl : 0);
+            goL = __ballot(innode && nd.go == SWD_GO_LEFT);
+            goR = __ballot(innode && nd.go == SWD_GO_RIGHT);
+        }
 #if defined(BH_TEAM_PROFILE)
-        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, tp_, &tp_t0_};
+        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR, tp_, &tp_t0_};
 #else
-        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt};
+        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR};
 #endif
         const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
         BH_TP(4);

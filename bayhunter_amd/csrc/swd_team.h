@@ -303,8 +303,8 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
     int left = 1;
     {
         const double wa = fabs(S.ceval - S.c1), wb = fabs(S.c2 - S.ceval), tol = 1.e-6 * fabs(S.ceval);
-        double w = wa > wb ? wa : wb;
-        while (w > tol && left < 6) { w *= 0.5; left++; }
+        const double w = wa > wb ? wa : wb;
+        left += (w > tol) + (w > 2.0 * tol) + (w > 4.0 * tol) + (w > 8.0 * tol) + (w > 16.0 * tol);
     }
     int depth = 0;
     while (depth < left - 1 && (4 << depth) - 1 <= cap) depth++;
@@ -409,6 +409,59 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
     *c = ok ? (mid ? 0.5 * (b + cn) : cn) : __builtin_nan("");
 }
 
+// ---- the bisection tree taken in one step -------------------------------------------------------
+// What nevill does with the value of tree node j once the search arrives there (the `mid` part of
+// swd_control, surfdisp96.f:599-640): the bracket update, the stopping test, and whether the next
+// point is a bisection -- then the search moves on to one of the node's two children -- or not (a
+// Neville step, or the root is found: the walk stops and swd_control itself takes over).  It only
+// depends on values of the node's ancestors, so lane j evaluates node j for all nodes at once and the
+// consuming loop follows the decisions down the tree instead of passing through swd_control once per
+// level.  `del(slot)` returns the period-equation value of a slot.
+enum { SWD_GO_LEFT = 0, SWD_GO_RIGHT = 1, SWD_GO_STOP = 2 };    // LEFT: c2 = c3 (child 2j+1), RIGHT: c1 = c3
+struct TeamwNode {
+    int go;
+    double c1, d1, c2, d2;        // the bracket the search has when it arrives at the node
+};
+template <class Del>
+BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const Del &del, int j)
+{
+    const double pct = (double)0.01f;
+    int l = 0;
+    while ((2 << l) - 1 <= j) l++;
+    const int pth = j + 1 - (1 << l);
+    TeamwNode n;
+    n.c1 = S.c1; n.d1 = S.del1; n.c2 = S.c2; n.d2 = S.del2;
+    double c3 = S.ceval;
+    // values of the ancestors (level m: slot ((j + 1) >> (l - m)) - 1), fetched together: the walk
+    // below is then arithmetic only
+    double da[4];
+    for (int m = 0; m < 4; m++) da[m] = del(m < l ? ((j + 1) >> (l - m)) - 1 : 0);
+    const double d3 = del(j);
+    for (int m = 0; m < 4; m++) {
+        if (m < l) {
+            const int bit = (pth >> (l - 1 - m)) & 1;
+            if (bit) { n.c1 = c3; n.d1 = da[m]; } else { n.c2 = c3; n.d2 = da[m]; }
+            c3 = 0.5 * (n.c1 + n.c2);
+        }
+    }
+    bool stop = false;
+    int nev = 1;                                    // (a node below the root is reached by a bisection)
+    if (j == 0) {
+        nev = S.nev;
+        if (S.st == SWD_ST_TOP)                     // label 100: step count, estimate outside the bracket
+            stop = S.nctrl + 1 >= 100 || c3 < dmin(n.c1, n.c2) || c3 > dmax(n.c1, n.c2);
+    }
+    const double s13 = n.d1 - d3, s32 = d3 - n.d2;
+    const bool neg = dsign1(d3) * dsign1(n.d1) < 0.0;
+    const double c1 = neg ? n.c1 : c3, d1 = neg ? n.d1 : d3, c2 = neg ? c3 : n.c2, d2 = neg ? d3 : n.d2;
+    if (fabs(c1 - c2) <= 1.e-6 * c1) stop = true;
+    if (dsign1(s13) != dsign1(s32)) nev = 0;
+    const double ss1 = fabs(d1), s1 = pct * ss1, ss2 = fabs(d2), s2 = pct * ss2;
+    if (!(s1 > ss2 || s2 > ss1 || nev == 0)) stop = true;       // a Neville step comes next
+    n.go = stop ? SWD_GO_STOP : neg ? SWD_GO_LEFT : SWD_GO_RIGHT;
+    return n;
+}
+
 // Stores a Rayleigh layer matrix column by column (column i at p + 6 i: ca(1..5, i)).
 BH_DEV void swd_teamw_store_dunkin(double *p, const Dunkin &a)
 {
@@ -487,23 +540,51 @@ BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, 
 //          `int run(int first, int stride, int count, bool neg)`: how many of the slots first,
 //          first + stride, ... (at most count) in a row are valid scan trials whose value has sign
 //          bit `neg`;
+//          `int go(const SwdState &, int j)`, `TeamwNode node(const SwdState &, int j)`: swd_teamw_node
+//          of tree node j for the state the round was planned with;
 //          `probe(int)`, `count(int, int)`: cycle probes of the diagnostic build, else empty.
 // Scan trials without a sign change are the bulk of all evaluations (two thirds) and
 // each costs a pass through swd_control although all it does is "c1 = c2, del1 = del2, next grid
 // point" (surfdisp96.f:461-470): a run of them is taken in one step.
+// A chain of bisections down the tree is taken in one step too (swd_teamw_node): the state is set to
+// what swd_control would have left on arrival at the last node of the chain, and swd_control runs for
+// that node only.  `tree` = false walks the tree one swd_control call per node (the replay checks that
+// both leave the same state).
 // Returns the number of values consumed (= evaluations of the reference).
 template <class Lay, class Src, class Vals, class Nev>
 BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const SwdTargetDev &tg,
-                             const double *BH_RESTRICT per, int wss, const TeamwRound &R, const Vals &vals)
+                             const double *BH_RESTRICT per, int wss, const TeamwRound &R, const Vals &vals,
+                             bool tree = true)
 {
     const double dc = (double)0.005f;
     int used = 0;
     while (used < R.nt) {
         // slot 0 IS the pending evaluation (no comparison: a NaN model has a NaN trial velocity, which
         // equals nothing, and the search must still advance -- to its bracketing step cap -- and end)
-        const int j = used == 0 ? 0 : vals.find(S.omega, S.ceval);
+        int j = used == 0 ? 0 : vals.find(S.omega, S.ceval);
         vals.probe(4);
         if (j < 0) break;
+        if (tree && used == 0 && R.nhalf > 0 && S.nctrl < 90) {       // (refinement round: ST_TOP / ST_MID)
+            int last = 0, lev = 0;
+            while (2 * last + 2 <= R.nhalf) {                         // `last` has children in the tree
+                const int go = vals.go(S, last);
+                if (go == SWD_GO_STOP) break;
+                last = 2 * last + 1 + go;
+                lev++;
+            }
+            if (lev > 0) {
+                const TeamwNode a = vals.node(S, last);
+                S.nctrl += lev - (S.st == SWD_ST_MID ? 1 : 0);        // (ST_MID does not count its step)
+                S.c1 = a.c1; S.del1 = a.d1; S.c2 = a.c2; S.del2 = a.d2;
+                S.del3 = vals.del((last - 1) >> 1);
+                S.c3 = vals.c(last);
+                S.ceval = S.c3;
+                S.nev = 1; S.m = 1; S.st = SWD_ST_TOP;
+                used = lev;
+                j = last;
+                vals.count(12, lev);
+            }
+        }
         if (S.st == SWD_ST_B && S.idir > 0 && R.ngrp > 0 && (R.nhalf == 0 || j > R.nhalf)) {
             const TeamwScan &g = swd_teamw_group(R, j);
             const int q = j - g.scan0, i = q / g.stride;

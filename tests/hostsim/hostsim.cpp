@@ -44,6 +44,14 @@ struct OneTask {
     void put(bh::SwdState &S, int k, int kmax, float v) { bh::swd_put_direct(S, k, kmax, v); }
     void fill_zero(bh::SwdState &S, int k, int kmax) { bh::swd_zero_direct(S, k, kmax); }
 };
+// task source of a consistency re-run that must not store anything
+struct NullSrc {
+    int next(HostLay &, double *&, double *&, double *&) { return 0; }
+    void done(int) {}
+    void sphere(HostLay &, int, int) {}
+    void put(bh::SwdState &, int, int, float) {}
+    void fill_zero(bh::SwdState &, int, int) {}
+};
 }  // namespace
 
 extern "C" int hs_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
@@ -116,6 +124,12 @@ struct ArrayVals {
     double c(int j) const { return tc[j]; }
     void probe(int) const {}
     void count(int, int) const {}
+    struct Del {
+        const double *dl;
+        double operator()(int j) const { return dl[j]; }
+    };
+    int go(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, Del{dl}, j).go; }
+    bh::TeamwNode node(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, Del{dl}, j); }
     int run(int first, int stride, int count, bool neg) const
     {
         int m = 0;
@@ -176,7 +190,25 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
             dl[j] = bh::swd_teamw_chain_one(lay, iwave, S, tc[j], tom[j], mats.data() + (size_t)j * nlm * bh::SWD_MAT);
         }
         ArrayVals vals{tc.data(), tom.data(), dl.data(), &R};
+        // the tree walk must leave the state one swd_control call per node leaves (checked as long as no
+        // root search ends inside the round: the driver stores results)
+        bh::SwdState Sq = S;
+        double qx[12], qy[12];
+        std::memcpy(qx, nx, sizeof(qx)); std::memcpy(qy, ny, sizeof(qy));
+        bh::NevMem qv{qx, qy};
+        const int k0 = S.k, pass0 = S.pass, iq0 = S.iq;
         nc += bh::swd_teamw_consume(S, nv, lay, src, tg, t, 1, R, vals);
+        if (S.k == k0 && S.pass == pass0 && S.iq == iq0 && S.st != bh::SWD_ST_DONE && S.ev == bh::SWD_EV_NONE) {
+            NullSrc nsrc;
+            bh::swd_teamw_consume(Sq, qv, lay, nsrc, tg, t, 1, R, vals, false);
+            auto same = [](double a, double b) { return a == b || (a != a && b != b); };
+            if (Sq.st != S.st || Sq.nev != S.nev || Sq.m != S.m || Sq.nctrl != S.nctrl || Sq.idir != S.idir ||
+                Sq.nbrk != S.nbrk || !same(Sq.c1, S.c1) || !same(Sq.c2, S.c2) || !same(Sq.c3, S.c3) ||
+                !same(Sq.del1, S.del1) || !same(Sq.del2, S.del2) || !same(Sq.del3, S.del3) ||
+                !same(Sq.ceval, S.ceval) || !same(Sq.omega, S.omega) ||
+                std::memcmp(qx, nx, sizeof(qx)) || std::memcmp(qy, ny, sizeof(qy)))
+                return -110;
+        }
         ns += nt;
         nr++;
     }

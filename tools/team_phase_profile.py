@@ -56,7 +56,8 @@ def main():
             print('   %-9s %8.0f cycles per round  (%4.1f %%)' % (n, v[i] / rounds, 100 * v[i] / tot))
         print('   total     %8.0f cycles per round, %.0f cycles per search; consumed %.2f of %.2f trials per round'
               % (tot / rounds, tot / nsearch, v[8] / rounds, v[9] / rounds))
-        print('   per round: %.2f fast-forward steps, %.2f control calls' % (v[10] / rounds, v[11] / rounds))
+        print('   per round: %.2f fast-forward steps, %.2f control calls, %.2f tree nodes taken without one'
+              % (v[10] / rounds, v[11] / rounds, v[12] / rounds))
     _lib.set_swd_kernel('auto')
 
 
