@@ -524,7 +524,9 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     int cap = 1, ja = 0, ra = 0;
     OneLay mine{0.f, 0.f, 0.f, 0.f}, half{0.f, 0.f, 0.f, 0.f};
     for (;;) {
-        swd_driver(S, lay, src, tg, perl, A.B, true);
+        // (no event pending in all but one round per search: do not even enter the driver's loop -- the
+        // copies between the two loop headers were 7 % of a round)
+        if (S.ev != SWD_EV_NONE) swd_driver(S, lay, src, tg, perl, A.B, true);
         if (S.st == SWD_ST_DONE) break;
         BH_TP(0);
         const int nlm = S.mmax - S.llw;
