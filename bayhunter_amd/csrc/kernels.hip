@@ -497,59 +497,143 @@ __device__ __forceinline__ double swd_teamw_chain_quad(const Lay &lay, const One
     return (S.llw != 1) ? swd_ray_water(lay, wvno, omega, e) : e[0];
 }
 
+// Task source of a wide team: one search per workgroup, its model already in LDS (loaded by all waves
+// before the control wave starts the driver).  Only the control wave uses it.
+struct WideSrc {
+    const SwdArgs &A;
+    const SwdTargetDev &tg;
+    int t, lane, nl, taken;
+    long b;
+    float *res;              // the search's results wait here (LDS, [nper]) and are written as one row at
+                             // the end: no global store inside the loop for a barrier to wait for
+    __device__ __forceinline__ int next(TeamLay &, double *&out, double *&cws, double *&cbws)
+    {
+        if (taken) return 0;
+        taken = 1;
+        out = A.out + b * A.out_stride + tg.out_off;
+        if (tg.mode > 1) {
+            cws = A.ws + ((long)t * 2 * BH_NP) * A.B + b;
+            cbws = cws + (long)BH_NP * A.B;
+        }
+        return nl;
+    }
+    __device__ __forceinline__ void done(int err)
+    {
+        if (lane == 0) A.err[b * A.ntargets + t] = err;
+        if (lane < tg.nper)                  // (lane 0 wrote res[]: same wave, program order)
+            A.out[b * A.out_stride + tg.out_off + lane] = (double)res[lane];
+    }
+    __device__ __forceinline__ void put(SwdState &, int k, int, float v) { if (lane == 0) res[k - 1] = v; }
+    __device__ __forceinline__ void fill_zero(SwdState &, int k, int kmax)
+    {
+        if (lane == 0)
+            for (int i = k; i <= kmax; i++) res[i - 1] = 0.f;
+    }
+    // the lanes of the control wave transform the shared copy in lock step (every lane reads a value
+    // before any lane writes it); the other waves are waiting at the round's first barrier
+    __device__ __forceinline__ void sphere(TeamLay &lay, int mmax, int ifunc) { swd_sphere(lay, mmax, ifunc); }
+};
+
+// Wave 0 is the control wave: it alone carries the search (driver, plan, matching, swd_control); the
+// other waves are workers that assemble and chain what the plan in LDS tells them and sleep at the
+// barrier while wave 0 thinks.  (Until round 2 every wave ran the control code redundantly: no
+// broadcast, but with two waves per SIMD -- a thousand searches of two waves each -- the redundant
+// control of one team competed with the arithmetic of another.)
 template <int W>
 __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
 {
     extern __shared__ double tlds[];
     constexpr int NL = SWD_T * W;
     const int lane = threadIdx.x, wl = lane & 63, wave = uni(lane >> 6);
+    const bool ctl = W == 1 || wave == 0;
     const int t = blockIdx.y;
     const SwdTargetDev tg = A.tg[t];
     const int nm = A.Lmax > NL ? A.Lmax : NL;
     double *mats = tlds, *dels = mats + (long)nm * SWD_MAT, *perl = dels + SWD_TEAMW_NT, *nevt = perl + BH_NP;
     double *tcl = nevt + 24 * W, *toml = tcl + SWD_TEAMW_NT;
     float *res = (float *)(toml + SWD_TEAMW_NT);                 // [BH_NP] staged results
+    int *hdr = (int *)(nevt + 24);                               // W > 1: {command, nt, mmax, llw} of the round
     TeamLay lay{res + BH_NP, A.Lmax};
-    // every wave runs the control code for itself: a Neville table per wave (the waves are not in
-    // step inside a phase)
-    NevMem nv{nevt + 24 * wave, nevt + 24 * wave + 12};
-    for (int k = lane; k < tg.nper; k += NL) perl[k] = A.periods[tg.per_off + k];   // (TeamSrc::next syncs)
-    TeamSrc src{A, tg, t, lane, NL, 0, (long)blockIdx.x, nullptr, res};
+    NevMem nv{nevt, nevt + 12};
+    // the team's one search: its model into LDS, by all waves
+    long b = blockIdx.x;
+    if (A.order) b = A.order[b];
+    const int nl = A.nlay[b];
+    if (nl < 1 || nl > A.Lmax) {
+        if (lane == 0) swd_bad_depth(A, tg, t, b);
+        return;
+    }
+    {
+        const long g = b * A.mstride;
+        for (int l = lane; l < nl; l += NL) {
+            lay.set_d(l, (float)A.h[g + l]);
+            lay.set_a(l, (float)A.vp[g + l]);
+            lay.set_b(l, (float)A.vs[g + l]);
+            lay.set_rho(l, (float)A.rho[g + l]);
+        }
+        for (int k = lane; k < tg.nper; k += NL) perl[k] = A.periods[tg.per_off + k];
+    }
+    __syncthreads();
+    WideSrc src{A, tg, t, lane, nl, 0, b, res};
     SwdState S;
     swd_state_init(S);
     TeamwNext nxt{-1, -1, 0.0};
     BH_TP_DECL;
     long rounds = 0;
-    const double *out_seen = nullptr;
+    bool first = true;
     int cap = 1, ja = 0, ra = 0;
     OneLay mine{0.f, 0.f, 0.f, 0.f}, half{0.f, 0.f, 0.f, 0.f};
+    TeamwRound R;
+    R.nt = 1; R.nhalf = 0; R.ngrp = 0;
+    double mc = 0.0, mom = 0.0;                                         // slot wl of the plan (control wave)
     for (;;) {
-        // (no event pending in all but one round per search: do not even enter the driver's loop -- the
-        // copies between the two loop headers were 7 % of a round)
-        if (S.ev != SWD_EV_NONE) swd_driver(S, lay, src, tg, perl, A.B, true);
-        if (S.st == SWD_ST_DONE) break;
-        BH_TP(0);
+        bool fin = false;
+        int nt = 1;
+        if (ctl) {
+            // (no event pending in all but one round per search: do not even enter the driver's loop --
+            // the copies between the two loop headers were 7 % of a round)
+            if (S.ev != SWD_EV_NONE) swd_driver(S, lay, src, tg, perl, A.B, true);
+            fin = S.st == SWD_ST_DONE;
+            BH_TP(0);
+            if (!fin) {
+                if (first) {
+                    const int nlm0 = S.mmax - S.llw;
+                    cap = nlm0 > 0 ? NL / nlm0 : SWD_TEAMW_NT;
+                    if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;        // one quad per Rayleigh trial
+                    if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
+                    if (cap < 1) cap = 1;
+                }
+                R = swd_teamw_round(S, tg, perl, cap, nxt);
+                nt = R.nt;
+                swd_teamw_trial(R, S, wl < nt ? wl : 0, &mc, &mom);
+                if (lane < nt) { tcl[lane] = mc; toml[lane] = mom; }
+            }
+            if (W > 1 && lane == 0) { hdr[0] = fin ? 1 : 0; hdr[1] = nt; hdr[2] = S.mmax; hdr[3] = S.llw; }
+        }
+        __syncthreads();
+        if (W > 1 && !ctl) {
+            fin = hdr[0] != 0;
+            nt = hdr[1];
+            S.mmax = hdr[2];
+            S.llw = hdr[3];
+        }
+        if (fin) break;
+        BH_TP(1);
         const int nlm = S.mmax - S.llw;
-        if (S.out != out_seen) {          // a new model: slots per round, and which (trial, layer) this lane assembles
-            out_seen = S.out;
+        if (first) {          // slots per round, and which (trial, layer) this lane assembles
+            first = false;
             cap = nlm > 0 ? NL / nlm : SWD_TEAMW_NT;
-            if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;            // one quad per Rayleigh trial
+            if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;
             if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
             if (cap < 1) cap = 1;
             ja = (cap > 1 && nlm > 0) ? lane / nlm : 0;
             ra = lane - ja * nlm;
-            // this lane's layer and the half-space, read from the shared copy once per model
+            // this lane's layer and the half-space, read from the shared copy once (after a possible
+            // earth-flattening transform by the control wave)
             const int i0 = S.llw - 1 + (ra < nlm ? ra : 0), ih = S.mmax - 1;
             mine = OneLay{lay.d(i0), lay.a(i0), lay.b(i0), lay.rho(i0)};
             half = OneLay{lay.d(ih), lay.a(ih), lay.b(ih), lay.rho(ih)};
         }
-        const TeamwRound R = swd_teamw_round(S, tg, perl, cap, nxt);
-        const int nt = R.nt;
-        double mc, mom;                                                 // slot wl of the plan
-        swd_teamw_trial(R, S, wl < nt ? wl : 0, &mc, &mom);
-        if (lane < nt) { tcl[lane] = mc; toml[lane] = mom; }
-        __syncthreads();
-        BH_TP(1);
         const int jq = 16 * wave + (wl >> 2);
         if (cap > 1) {
             if (ja < nt && nlm > 0) {
@@ -558,11 +642,12 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
                     swd_teamw_assemble_one(mine, tg.iwave, S, ra, ac, toml[ja], mats + (long)lane * SWD_MAT);
             }
         } else {
+            const double c0 = tcl[0], om0 = toml[0];
             for (int r = lane; r < nlm; r += NL)
-                swd_teamw_assemble_one(lay, tg.iwave, S, r, S.ceval, S.omega, mats + (long)r * SWD_MAT);
+                swd_teamw_assemble_one(lay, tg.iwave, S, r, c0, om0, mats + (long)r * SWD_MAT);
         }
         const bool qvalid = jq < nt;
-        const double qc = qvalid ? tcl[jq] : S.ceval, qom = qvalid ? toml[jq] : S.omega;
+        const double qc = tcl[qvalid ? jq : 0], qom = toml[qvalid ? jq : 0];
         __syncthreads();
         BH_TP(2);
         if (tg.iwave == 2) {
@@ -573,28 +658,30 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         }
         __syncthreads();
         BH_TP(3);
-        // refinement round: lane j evaluates node j of the bisection tree (what the search does when it
-        // arrives there), the consuming loop then follows the decisions
-        TeamwNode nd;
-        nd.go = SWD_GO_STOP; nd.c1 = nd.d1 = nd.c2 = nd.d2 = 0.0;
-        unsigned long long goL = 0, goR = 0;
-        if (R.nhalf > 0) {
-            const bool innode = wl <= R.nhalf;
-            nd = swd_teamw_node(S, LdsDel{dels}, innode ? wl : 0);
-            goL = __ballot(innode && nd.go == SWD_GO_LEFT);
-            goR = __ballot(innode && nd.go == SWD_GO_RIGHT);
-        }
+        if (ctl) {
+            // refinement round: lane j evaluates node j of the bisection tree (what the search does when
+            // it arrives there), the consuming loop then follows the decisions
+            TeamwNode nd;
+            nd.go = SWD_GO_STOP; nd.c1 = nd.d1 = nd.c2 = nd.d2 = 0.0;
+            unsigned long long goL = 0, goR = 0;
+            if (R.nhalf > 0) {
+                const bool innode = wl <= R.nhalf;
+                nd = swd_teamw_node(S, LdsDel{dels}, innode ? wl : 0);
+                goL = __ballot(innode && nd.go == SWD_GO_LEFT);
+                goR = __ballot(innode && nd.go == SWD_GO_RIGHT);
+            }
 #if defined(BH_TEAM_PROFILE)
-        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR, tp_, &tp_t0_};
+            TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR, tp_, &tp_t0_};
 #else
-        TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR};
+            TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR};
 #endif
-        const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
-        BH_TP(4);
-        BH_TP_COUNT(8, used);
-        BH_TP_COUNT(9, nt);
-        (void)used;
-        rounds++;
+            const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
+            BH_TP(4);
+            BH_TP_COUNT(8, used);
+            BH_TP_COUNT(9, nt);
+            (void)used;
+            rounds++;
+        }
     }
     BH_TP_FLUSH(rounds);
     (void)rounds;
