@@ -286,14 +286,14 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     const long cus = resident > 0 ? resident / 8 : 256;
     struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
     static const Form forms[8] = {
-        {0,   {4.47, 6.29, 10.9, 15.6, 31.7}, {24638, 15294, 8131, 5540, 3382}},    // lane kernel
-        {8,   {2.67, 3.5, 6.07, 7.01, 12.5},  {5990, 4045, 2357, 1590, 750}},
-        {16,  {2.12, 2.69, 4.95, 6.03, 10.6}, {3715, 2695, 1472, 1154, 951}},
-        {32,  {1.68, 1.93, 2.86, 4.0, 9.07},  {2398, 1895, 1262, 860, 675}},
-        {64,  {0.69, 0.68, 1.05, 1.67, 3.81}, {3022, 2736, 1755, 1082, 873}},
-        {128, {0.6, 0.58, 0.91, 1.17, 2.23},  {1558, 1340, 865, 644, 447}},
-        {256, {0.61, 0.59, 0.78, 0.96, 1.62}, {857, 774, 594, 471, 357}},
-        {512, {0.71, 0.7, 0.9, 1.02, 1.71},   {418, 378, 303, 263, 194}},
+        {0,   {4.44, 6.07, 11.1, 15.6, 31.1}, {24731, 15259, 8238, 5530, 3422}},    // lane kernel
+        {8,   {2.52, 3.6, 6.17, 7.1, 12.3},   {6024, 4035, 2351, 1581, 748}},
+        {16,  {2.11, 2.64, 5.01, 5.99, 10.6}, {3682, 2677, 1469, 1152, 942}},
+        {32,  {1.67, 1.95, 2.87, 3.98, 8.94}, {2395, 1882, 1260, 855, 673}},
+        {64,  {0.62, 0.62, 0.97, 1.59, 3.63}, {3309, 2919, 1857, 1118, 905}},
+        {128, {0.52, 0.52, 0.86, 1.13, 2.22}, {1916, 1588, 951, 681, 465}},
+        {256, {0.52, 0.52, 0.71, 0.9, 1.54},  {1069, 914, 664, 499, 379}},
+        {512, {0.56, 0.56, 0.76, 0.88, 1.55}, {543, 478, 364, 309, 223}},
     };
     const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
     bool team = false;
