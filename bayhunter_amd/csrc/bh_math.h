@@ -49,6 +49,17 @@ BH_DEV double bh_rint(double x) { return __builtin_rint(x); }
 BH_DEV double bh_ldexp(double x, int k) { return __builtin_amdgcn_ldexp(x, k); }
 #endif
 
+// x if two == 0, -x if two == 2: the sign bit flipped by an integer xor (three instructions instead of
+// compare + select + xor; -x is exactly a flip of the sign bit, for zeros and NaNs too)
+#if defined(BH_HOSTSIM)
+BH_DEV double bh_negate_if2(double x, int two) { return two ? -x : x; }
+#else
+BH_DEV double bh_negate_if2(double x, int two)
+{
+    return __hiloint2double(__double2hiint(x) ^ (two << 30), __double2loint(x));
+}
+#endif
+
 #if defined(BH_HOSTSIM) && defined(BH_HOSTSIM_GLIBC_MATH)
 // tests/hostsim "exact" build: glibc's functions, so that the replay is bit-identical to the oracle
 BH_DEV void bh_sincos(double x, double *sn, double *cs) { *sn = std::sin(x); *cs = std::cos(x); }
@@ -113,8 +124,8 @@ BH_DEV void bh_sincos(double x, double *sn, double *cs)
     // quadrant
     double so = (n & 1) ? c : s;
     double co = (n & 1) ? s : c;
-    *sn = (n & 2) ? -so : so;
-    *cs = ((n + 1) & 2) ? -co : co;
+    *sn = bh_negate_if2(so, n & 2);
+    *cs = bh_negate_if2(co, (n + 1) & 2);
 }
 
 BH_DEV double bh_exp(double x)
