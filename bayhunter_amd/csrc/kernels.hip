@@ -147,6 +147,47 @@ struct QueueSrc {
 #ifndef BH_SWD_WAVES
 #define BH_SWD_WAVES 2            // waves per SIMD the register budget of swd_kernel is set for
 #endif
+// Diagnostic build only (-DBH_LANE_PROFILE, tools/lane_phase_profile.py): shader-clock cycles of the three
+// parts of swd_lane's loop -- driver (events, task fetch), period equation, control -- summed over all
+// lanes (a lane also counts the cycles it sits masked off while other lanes of its wave run their
+// control code); read back with bh_debug_lane_profile.
+#if defined(BH_LANE_PROFILE)
+__device__ unsigned long long g_lane_prof[8];
+template <class Lay, class Src>
+__device__ __forceinline__ void swd_lane_prof(Lay &lay, Src &src, const SwdTargetDev &tg, const double *BH_RESTRICT per, int wss)
+{
+    SwdState S;
+    swd_state_init(S);
+    NevRegs nv;
+    swd_nev_init(nv);
+    unsigned long long td = 0, te = 0, tc = 0, n = 0, t0 = clock64(), t1;
+    for (;;) {
+        swd_events(S, lay, src, tg, per, wss);
+        t1 = clock64(); td += t1 - t0; t0 = t1;
+        if (S.st == SWD_ST_DONE) break;
+        const double wvno = S.omega / S.ceval;
+        const double del = (tg.iwave == 1) ? swd_dltar1(lay, S.mmax, S.llw, wvno, S.omega)
+                                           : swd_dltar4(lay, S.mmax, S.llw, wvno, S.omega);
+        t1 = clock64(); te += t1 - t0; t0 = t1;
+        swd_control(S, del, nv);
+        t1 = clock64(); tc += t1 - t0; t0 = t1;
+        n++;
+    }
+    atomicAdd(&g_lane_prof[0], td);
+    atomicAdd(&g_lane_prof[1], te);
+    atomicAdd(&g_lane_prof[2], tc);
+    atomicAdd(&g_lane_prof[3], n);
+}
+extern "C" int bh_debug_lane_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_prof), sizeof(g_lane_prof)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(BH_SWD_WAVES, BH_SWD_WAVES))) void swd_kernel(SwdArgs A)
 {
     extern __shared__ float lds[];
@@ -154,7 +195,16 @@ __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(BH_SWD_WA
     const SwdTargetDev tg = A.tg[t];
     LdsLay lay{lds + threadIdx.x, A.Lmax};
     QueueSrc src{A, tg, A.counters + t, t, 0, A.stage ? lds + 4 * A.Lmax * SWD_T + threadIdx.x : nullptr};
-    swd_lane(lay, src, tg, A.periods + tg.per_off, A.B, nullptr);
+    // the target's periods in LDS, behind the model and result images: a lane reads one whenever it
+    // starts a period, and in most loop trips some lane of the wave does
+    double *perl = (double *)(lds + (4 * A.Lmax + A.stage) * SWD_T);
+    for (int k = threadIdx.x; k < tg.nper; k += SWD_T) perl[k] = A.periods[tg.per_off + k];
+    __syncthreads();
+#if defined(BH_LANE_PROFILE)
+    swd_lane_prof(lay, src, tg, perl, A.B);
+#else
+    swd_lane(lay, src, tg, perl, A.B, nullptr);
+#endif
 }
 
 // ---------------------------------------------------------------------------------- SWD, team form
@@ -303,7 +353,7 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
         bool live = true;
         for (;;) {
             if (live) {
-                swd_driver(S, lay, src, tg, per, A.B);
+                swd_events(S, lay, src, tg, per, A.B);
                 live = S.st != SWD_ST_DONE;
             }
             if (!__any(live)) break;
@@ -885,11 +935,13 @@ hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
     size_t lds = (size_t)4 * A.Lmax * SWD_T * sizeof(float);
     int maxper = 0;
     for (int t = 0; t < A.ntargets; t++) maxper = A.tg[t].nper > maxper ? A.tg[t].nper : maxper;
+    const size_t perbytes = (size_t)BH_NP * sizeof(double);                      // the target's periods
     const size_t staged = lds + (size_t)maxper * SWD_T * sizeof(float);
     SwdArgs B = A;
     static const bool no_stage = std::getenv("BH_SWD_NO_STAGE") != nullptr;      // A/B switch (diagnostic)
-    B.stage = (!no_stage && maxper > 0 && 8 * staged <= 160 * 1024) ? maxper : 0;   // periods staged per lane
+    B.stage = (!no_stage && maxper > 0 && 8 * (staged + perbytes) <= 160 * 1024) ? maxper : 0;   // periods staged per lane
     if (B.stage) lds = staged;
+    lds += perbytes;
     static size_t lds_set[16] = {0};
     hipError_t e0 = ensure_dyn_lds((const void *)swd_kernel, lds, lds_set);
     if (e0 != hipSuccess) return e0;

@@ -512,6 +512,87 @@ BH_DEV double swd_bracket_next(double &c1, int &idir, double clow, double dc)
     return c2;
 }
 
+// ---- the two common events of a search (bodies of swd_driver's branches) ---------------------------
+// A period begins (k <= kmax, k < ift): periods, start value and lower bound of the search,
+// surfdisp96.f:231-271.
+BH_DEV void swd_on_begin_period(SwdState &S, const SwdTargetDev &tg, const double *BH_RESTRICT per, int wss)
+{
+    const double TWOPI = 2.0 * 3.141592653589793;
+    const double one = 1.0e-2;
+    const double onea = 1.5;                        // dble(sone), sone = 1.5 (real*4)
+    const double dc = (double)0.005f;               // dabs(dble(ddc)), ddc = 0.005 (real*4)
+    const float h = 0.005f;
+    double t1 = per[S.k - 1];
+    if (tg.igr > 0) {
+        S.t1a = (float)(t1 / (double)(1.f + h));
+        S.t1b = (float)(t1 / (double)(1.f - h));
+        t1 = (double)S.t1a;
+    } else {
+        S.t1a = (float)t1;
+    }
+    if (S.k == 1 && S.iq == 1) { S.c1 = S.cc; S.clow = S.cc; S.ifirst = 1; }
+    else if (S.k == 1) { S.c1 = S.cws[0] + one * dc; S.clow = S.c1; S.ifirst = 1; }
+    else if (S.iq > 1) {
+        S.ifirst = 0;
+        S.clow = S.cws[(S.k - 1) * wss] + one * dc;
+        S.c1 = S.cprev;
+        if (S.c1 < S.clow) S.c1 = S.clow;
+    } else {
+        S.ifirst = 0;
+        S.c1 = S.cprev - onea * dc;
+        S.clow = S.cc;                        // clow = cm
+    }
+    S.pass = 0;
+    S.omega = TWOPI / t1;
+    S.ceval = S.c1;
+    S.st = SWD_ST_A;
+    S.ev = SWD_EV_NONE;
+}
+
+// A root search has ended (SOLVED, or NOROOT on the second solve of a group-velocity pair): the
+// second solve is set up, or the period's value is stored and the next period announced,
+// surfdisp96.f:273-312.
+template <class Src>
+BH_DEV void swd_on_solved(SwdState &S, Src &src, const SwdTargetDev &tg, int wss)
+{
+    const double TWOPI = 2.0 * 3.141592653589793;
+    const double one = 1.0e-2;
+    const double onea = 1.5;
+    const double dc = (double)0.005f;
+    const int igr = tg.igr, kmax = tg.nper;
+    const bool multimode = tg.mode > 1;
+    if (S.pass == 0) {
+        S.ck = S.c1;                          // c(k) = c1
+        if (multimode) S.cws[(S.k - 1) * wss] = S.ck;
+        if (igr > 0) {                        // second solve at t1b, surfdisp96.f:282-294
+            double t1 = (double)S.t1b;
+            S.ifirst = 0;
+            S.clow = (multimode ? S.cbws[(S.k - 1) * wss] : 0.0) + one * dc;
+            S.c1 = S.c1 - onea * dc;
+            S.pass = 1;
+            S.omega = TWOPI / t1;
+            S.ceval = S.c1;
+            S.st = SWD_ST_A;
+            S.ev = SWD_EV_NONE;
+            return;
+        }
+        S.c1 = 0.0;
+    } else {
+        if (S.ev == SWD_EV_NOROOT) S.c1 = S.ck;   // root not found at the larger period
+        if (multimode) S.cbws[(S.k - 1) * wss] = S.c1;
+    }
+    float cc0 = (float)S.ck, cc1b = (float)S.c1;
+    if (igr == 0) {
+        src.put(S, S.k, kmax, cc0);
+    } else {
+        float gvel = (1 / S.t1a - 1 / S.t1b) / (1 / (S.t1a * cc0) - 1 / (S.t1b * cc1b));
+        src.put(S, S.k, kmax, gvel);
+    }
+    S.cprev = S.ck;
+    S.k++;
+    S.ev = SWD_EV_BEGIN_PERIOD;
+}
+
 // ---- driver: task / period / pass / mode bookkeeping (surfdisp96.f:96-355) ------------------------
 // Consumes the pending event(s) until the search needs a period-equation value (S.st != DONE, then
 // S.omega / S.ceval say where) or the task source is drained (S.st == SWD_ST_DONE).
@@ -531,12 +612,8 @@ template <class Lay, class Src>
 BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
                        const double *BH_RESTRICT per, int wss, bool allow_fetch = true)
 {
-    const double TWOPI = 2.0 * 3.141592653589793;
-    const double one = 1.0e-2;
-    const double onea = 1.5;                        // dble(sone), sone = 1.5 (real*4)
     const double dc = (double)0.005f;               // dabs(dble(ddc)), ddc = 0.005 (real*4)
-    const float h = 0.005f;
-    const int ifunc = tg.iwave, igr = tg.igr, kmax = tg.nper, nmode = tg.mode;
+    const int ifunc = tg.iwave, kmax = tg.nper, nmode = tg.mode;
     const bool multimode = nmode > 1;
     while (S.ev != SWD_EV_NONE) {
         if (S.ev == SWD_EV_FETCH) {                   // surfdisp96.f:96-222 for the next model
@@ -573,62 +650,9 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
                 continue;
             }
             if (S.k >= S.ift) { S.ev = SWD_EV_NOROOT; S.pass = 0; continue; }
-            double t1 = per[S.k - 1];
-            if (igr > 0) {
-                S.t1a = (float)(t1 / (double)(1.f + h));
-                S.t1b = (float)(t1 / (double)(1.f - h));
-                t1 = (double)S.t1a;
-            } else {
-                S.t1a = (float)t1;
-            }
-            if (S.k == 1 && S.iq == 1) { S.c1 = S.cc; S.clow = S.cc; S.ifirst = 1; }
-            else if (S.k == 1) { S.c1 = S.cws[0] + one * dc; S.clow = S.c1; S.ifirst = 1; }
-            else if (S.iq > 1) {
-                S.ifirst = 0;
-                S.clow = S.cws[(S.k - 1) * wss] + one * dc;
-                S.c1 = S.cprev;
-                if (S.c1 < S.clow) S.c1 = S.clow;
-            } else {
-                S.ifirst = 0;
-                S.c1 = S.cprev - onea * dc;
-                S.clow = S.cc;                        // clow = cm
-            }
-            S.pass = 0;
-            S.omega = TWOPI / t1;
-            S.ceval = S.c1;
-            S.st = SWD_ST_A;
-            S.ev = SWD_EV_NONE;
+            swd_on_begin_period(S, tg, per, wss);
         } else if (S.ev == SWD_EV_SOLVED || (S.ev == SWD_EV_NOROOT && S.pass == 1)) {
-            if (S.pass == 0) {
-                S.ck = S.c1;                          // c(k) = c1
-                if (multimode) S.cws[(S.k - 1) * wss] = S.ck;
-                if (igr > 0) {                        // second solve at t1b, surfdisp96.f:282-294
-                    double t1 = (double)S.t1b;
-                    S.ifirst = 0;
-                    S.clow = (multimode ? S.cbws[(S.k - 1) * wss] : 0.0) + one * dc;
-                    S.c1 = S.c1 - onea * dc;
-                    S.pass = 1;
-                    S.omega = TWOPI / t1;
-                    S.ceval = S.c1;
-                    S.st = SWD_ST_A;
-                    S.ev = SWD_EV_NONE;
-                    continue;
-                }
-                S.c1 = 0.0;
-            } else {
-                if (S.ev == SWD_EV_NOROOT) S.c1 = S.ck;   // root not found at the larger period
-                if (multimode) S.cbws[(S.k - 1) * wss] = S.c1;
-            }
-            float cc0 = (float)S.ck, cc1b = (float)S.c1;
-            if (igr == 0) {
-                src.put(S, S.k, kmax, cc0);
-            } else {
-                float gvel = (1 / S.t1a - 1 / S.t1b) / (1 / (S.t1a * cc0) - 1 / (S.t1b * cc1b));
-                src.put(S, S.k, kmax, gvel);
-            }
-            S.cprev = S.ck;
-            S.k++;
-            S.ev = SWD_EV_BEGIN_PERIOD;
+            swd_on_solved(S, src, tg, wss);
         } else {                                      // NOROOT on the first solve: label 1700
             if (S.iq <= 1) S.err = 1;
             S.ift = S.k;
@@ -638,6 +662,24 @@ BH_DEV void swd_driver(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
             else S.ev = SWD_EV_BEGIN_PERIOD;
         }
     }
+}
+
+// The pending event(s) of a search, the common chain first: "root found -> value stored -> next period"
+// is two straight-line blocks; only the rare events (task fetch, no root, end of the periods / of a
+// mode) enter the driver's loop.  In a wave of the throughput kernel some lane ends a period in 86 %
+// of the loop trips, and the loop -- an if-chain per trip, two trips per chain, the whole search state
+// copied between loop headers -- was 10.6 % of the kernel's lane-cycles (tools/lane_phase_profile.py).
+// Same operations in the same order as swd_driver alone.
+template <class Lay, class Src>
+BH_DEV void swd_events(SwdState &S, Lay &lay, Src &src, const SwdTargetDev &tg,
+                       const double *BH_RESTRICT per, int wss, bool allow_fetch = true)
+{
+#if !defined(BH_NO_FAST_EVENTS)                   // (A/B switch: the driver's loop for every event)
+    if (S.ev == SWD_EV_SOLVED || (S.ev == SWD_EV_NOROOT && S.pass == 1)) swd_on_solved(S, src, tg, wss);
+    if (S.ev == SWD_EV_BEGIN_PERIOD && S.k <= tg.nper && S.k < S.ift) swd_on_begin_period(S, tg, per, wss);
+    if (S.ev != SWD_EV_NONE)
+#endif
+        swd_driver(S, lay, src, tg, per, wss, allow_fetch);
 }
 
 // ---- control: getsol + nevill as a resumable machine, fed the period-equation value at S.ceval -----
@@ -732,7 +774,7 @@ BH_DEV void swd_lane(Lay &lay, Src &src, const SwdTargetDev &tg, const double *B
     swd_nev_init(nv);
     long nc = 0;
     for (;;) {
-        swd_driver(S, lay, src, tg, per, wss);
+        swd_events(S, lay, src, tg, per, wss);
         if (S.st == SWD_ST_DONE) break;
         double wvno = S.omega / S.ceval;
         double del = (tg.iwave == 1) ? swd_dltar1(lay, S.mmax, S.llw, wvno, S.omega)

@@ -602,7 +602,7 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
                     if (S.c1 < S.cc || S.c1 >= S.cfail) {
                         S.nbrk += m - 1;
                         S.ev = SWD_EV_NOROOT;
-                        swd_driver(S, lay, src, tg, per, wss, false);
+                        swd_events(S, lay, src, tg, per, wss, false);
                         if (S.st == SWD_ST_DONE) break;
                     } else {
                         S.nbrk += m;
@@ -620,7 +620,7 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
         vals.probe(6);
         vals.count(11, 1);
         if (S.ev != SWD_EV_NONE) {
-            swd_driver(S, lay, src, tg, per, wss, false);
+            swd_events(S, lay, src, tg, per, wss, false);
             vals.probe(7);
             if (S.st == SWD_ST_DONE) break;          // task finished: the next model is fetched by the caller
         }
