@@ -85,6 +85,14 @@ BH_DEV double xsqrt(double x)
 #endif
 
 BH_DEV double dsign1(double x) { return copysign(1.0, x); }
+// dsign(1, a) != dsign(1, b), equivalently dsign(1, a) * dsign(1, b) < 0 (the reference's sign tests,
+// surfdisp96.f:431,461,600,616): the sign bits differ.  One xor instead of two copysigns and a product;
+// the same truth value for every pair of operands, zeros and NaNs included.
+#if defined(BH_HOSTSIM)
+BH_DEV bool bh_signs_differ(double a, double b) { return std::signbit(a) != std::signbit(b); }
+#else
+BH_DEV bool bh_signs_differ(double a, double b) { return (__double2hiint(a) ^ __double2hiint(b)) < 0; }
+#endif
 BH_DEV double bh_fmax(double a, double b) { return __builtin_fmax(a, b); }
 BH_DEV double dmin(double a, double b) { return a < b ? a : b; }
 BH_DEV double dmax(double a, double b) { return a > b ? a : b; }

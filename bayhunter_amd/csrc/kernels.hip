@@ -78,6 +78,9 @@ struct QueueSrc {
             // (Handing the queue out in chunks of 64 consecutive slots per wave, so that a wave holds
             // neighbours of the processing order, was measured: 5.7 % slower -- slots reserved by a
             // wave whose lanes are still busy wait while other waves idle at the end.  DESIGN section 4.1.)
+            // (Taking the slot a dozen evaluations before the search ends and walking these three dependent
+            // steps one per loop trip -- no wait for the atomic, the order and the depth -- was tried:
+            // no difference, 49.8 vs 49.2 ms on different boxes, driver share 6.6 % either way.)
             b = atomicAdd(counter, 1u);
             if (b >= (unsigned int)A.B) return 0;
             if (A.order) b = (unsigned int)A.order[b];
@@ -88,14 +91,36 @@ struct QueueSrc {
         cur = b;
         const long g = (long)b * A.mstride;
         if (A.vec2) {   // rows 16-byte aligned: two layers per load (half the memory requests)
-            for (int l = 0; l < nl; l += 2) {
-                const double2 h2 = *(const double2 *)(A.h + g + l), a2 = *(const double2 *)(A.vp + g + l),
-                              b2 = *(const double2 *)(A.vs + g + l), r2 = *(const double2 *)(A.rho + g + l);
-                lay.set_d(l, (float)h2.x); lay.set_a(l, (float)a2.x);
-                lay.set_b(l, (float)b2.x); lay.set_rho(l, (float)r2.x);
-                if (l + 1 < nl) {
-                    lay.set_d(l + 1, (float)h2.y); lay.set_a(l + 1, (float)a2.y);
-                    lay.set_b(l + 1, (float)b2.y); lay.set_rho(l + 1, (float)r2.y);
+            // All loads of a chunk (12 layers of two arrays) are issued before the first value is used: a
+            // fetch stalls the whole wave for the memory latency of these rows -- they come from HBM, every
+            // model is read once -- and the plain loop (4 loads, wait, store, next pair of layers) paid it
+            // once per pair of layers: 5 round trips for 10 layers, now 2.
+            constexpr int CH = 6;
+            for (int l0 = 0; l0 < nl; l0 += 2 * CH) {
+                double2 p[CH], q[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++)
+                    if (l0 + 2 * u < nl) {
+                        p[u] = *(const double2 *)(A.h + g + l0 + 2 * u);
+                        q[u] = *(const double2 *)(A.vp + g + l0 + 2 * u);
+                    }
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const int l = l0 + 2 * u;
+                    if (l < nl) { lay.set_d(l, (float)p[u].x); lay.set_a(l, (float)q[u].x); }
+                    if (l + 1 < nl) { lay.set_d(l + 1, (float)p[u].y); lay.set_a(l + 1, (float)q[u].y); }
+                }
+#pragma unroll
+                for (int u = 0; u < CH; u++)
+                    if (l0 + 2 * u < nl) {
+                        p[u] = *(const double2 *)(A.vs + g + l0 + 2 * u);
+                        q[u] = *(const double2 *)(A.rho + g + l0 + 2 * u);
+                    }
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const int l = l0 + 2 * u;
+                    if (l < nl) { lay.set_b(l, (float)p[u].x); lay.set_rho(l, (float)q[u].x); }
+                    if (l + 1 < nl) { lay.set_b(l + 1, (float)p[u].y); lay.set_rho(l + 1, (float)q[u].y); }
                 }
             }
         } else {
@@ -160,6 +185,7 @@ __device__ __forceinline__ void swd_lane_prof(Lay &lay, Src &src, const SwdTarge
     swd_state_init(S);
     NevRegs nv;
     swd_nev_init(nv);
+    nv.cycles = 0;
     unsigned long long td = 0, te = 0, tc = 0, n = 0, t0 = clock64(), t1;
     for (;;) {
         swd_events(S, lay, src, tg, per, wss);
@@ -177,6 +203,7 @@ __device__ __forceinline__ void swd_lane_prof(Lay &lay, Src &src, const SwdTarge
     atomicAdd(&g_lane_prof[1], te);
     atomicAdd(&g_lane_prof[2], tc);
     atomicAdd(&g_lane_prof[3], n);
+    atomicAdd(&g_lane_prof[4], nv.cycles);
 }
 extern "C" int bh_debug_lane_profile(unsigned long long *out, int reset)
 {

@@ -403,6 +403,10 @@ struct SwdState {
 struct NevRegs {
     double x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11;
     double y1, y2, y3, y4, y5, y6, y7, y8, y9, y10, y11;
+#if defined(BH_LANE_PROFILE)
+    unsigned long long cycles;        // diagnostic build: shader-clock cycles the WAVE spends in swd_neville
+                                      // (booked on the first lane that takes the step)
+#endif
 };
 struct NevMem {
     double *x, *y;
@@ -423,14 +427,23 @@ BH_DEV void swd_nev_init(NevMem &n)
 BH_DEV bool swd_neville(NevRegs &n, int &m, bool nev2, double c1, double del1, double c2, double del2,
                         double c3, double del3, double *x1)
 {
+#if defined(BH_LANE_PROFILE)
+    const unsigned long long lp_t0 = clock64();
+#endif
     double ym1;                       // y(m+1)
     if (nev2) {                       // x(m+1)=c3, y(m+1)=del3
         ym1 = del3;
-        if (m == 1) { n.x2 = c3; n.y2 = del3; } else if (m == 2) { n.x3 = c3; n.y3 = del3; }
-        else if (m == 3) { n.x4 = c3; n.y4 = del3; } else if (m == 4) { n.x5 = c3; n.y5 = del3; }
-        else if (m == 5) { n.x6 = c3; n.y6 = del3; } else if (m == 6) { n.x7 = c3; n.y7 = del3; }
-        else if (m == 7) { n.x8 = c3; n.y8 = del3; } else if (m == 8) { n.x9 = c3; n.y9 = del3; }
-        else if (m == 9) { n.x10 = c3; n.y10 = del3; } else { n.x11 = c3; n.y11 = del3; }
+        // (tables longer than three points are rare: the two outer tests let a wave skip them)
+        if (m <= 3) {
+            if (m == 1) { n.x2 = c3; n.y2 = del3; } else if (m == 2) { n.x3 = c3; n.y3 = del3; }
+            else { n.x4 = c3; n.y4 = del3; }
+        } else if (m <= 6) {
+            if (m == 4) { n.x5 = c3; n.y5 = del3; } else if (m == 5) { n.x6 = c3; n.y6 = del3; }
+            else { n.x7 = c3; n.y7 = del3; }
+        } else {
+            if (m == 7) { n.x8 = c3; n.y8 = del3; } else if (m == 8) { n.x9 = c3; n.y9 = del3; }
+            else if (m == 9) { n.x10 = c3; n.y10 = del3; } else { n.x11 = c3; n.y11 = del3; }
+        }
     } else {
         n.x1 = c1; n.y1 = del1; n.x2 = c2; n.y2 = del2; m = 1;
         ym1 = del2;
@@ -444,18 +457,28 @@ BH_DEV bool swd_neville(NevRegs &n, int &m, bool nev2, double c1, double del1, d
         if (fabs(denom) < guard) bad = true;                                      \
         else n.XJ = (-n.YJ * n.XJ1 + ym1 * n.XJ) / denom;                         \
     }
-    BH_NEV_STEP(10, x10, y10, x11)
-    BH_NEV_STEP(9, x9, y9, x10)
-    BH_NEV_STEP(8, x8, y8, x9)
-    BH_NEV_STEP(7, x7, y7, x8)
-    BH_NEV_STEP(6, x6, y6, x7)
-    BH_NEV_STEP(5, x5, y5, x6)
-    BH_NEV_STEP(4, x4, y4, x5)
+    if (m >= 7) {
+        BH_NEV_STEP(10, x10, y10, x11)
+        BH_NEV_STEP(9, x9, y9, x10)
+        BH_NEV_STEP(8, x8, y8, x9)
+        BH_NEV_STEP(7, x7, y7, x8)
+    }
+    if (m >= 4) {
+        BH_NEV_STEP(6, x6, y6, x7)
+        BH_NEV_STEP(5, x5, y5, x6)
+        BH_NEV_STEP(4, x4, y4, x5)
+    }
     BH_NEV_STEP(3, x3, y3, x4)
     BH_NEV_STEP(2, x2, y2, x3)
     BH_NEV_STEP(1, x1, y1, x2)
 #undef BH_NEV_STEP
     *x1 = n.x1;
+#if defined(BH_LANE_PROFILE)
+    {
+        const unsigned long long act = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) n.cycles += clock64() - lp_t0;
+    }
+#endif
     return !bad;
 }
 BH_DEV bool swd_neville(NevMem &n, int &m, bool nev2, double c1, double del1, double c2, double del2,
@@ -692,13 +715,13 @@ BH_DEV void swd_control(SwdState &S, double del, Nev &nv)
     if (S.st == SWD_ST_A) {                           // getsol entry, surfdisp96.f:426-438
         S.del1 = del;
         if (S.ifirst == 1) S.del1st = S.del1;
-        double plmn = dsign1(S.del1st) * dsign1(S.del1);
-        S.idir = (S.ifirst == 1 || plmn >= 0.0) ? +1 : -1;
+        // plmn = dsign(1, del1st) * dsign(1, del1); idir = -1 iff plmn < 0
+        S.idir = (S.ifirst == 1 || !bh_signs_differ(S.del1st, S.del1)) ? +1 : -1;
         S.nbrk = 0;
         bracket_step = true;
     } else if (S.st == SWD_ST_B) {                    // surfdisp96.f:461-470
         S.del2 = del;
-        if (dsign1(S.del1) != dsign1(S.del2)) {       // bracketed -> nevill: first half (:583)
+        if (bh_signs_differ(S.del1, S.del2)) {        // bracketed -> nevill: first half (:583)
             S.c3 = 0.5 * (S.c1 + S.c2);
             S.nev = 1; S.nctrl = 1;
             S.ceval = S.c3; S.st = SWD_ST_TOP;
@@ -723,11 +746,11 @@ BH_DEV void swd_control(SwdState &S, double del, Nev &nv)
         }
         if (mid && !finish) {                         // surfdisp96.f:599-669
             double s13 = S.del1 - S.del3, s32 = S.del3 - S.del2;
-            if (dsign1(S.del3) * dsign1(S.del1) < 0.0) { S.c2 = S.c3; S.del2 = S.del3; }
+            if (bh_signs_differ(S.del3, S.del1)) { S.c2 = S.c3; S.del2 = S.del3; }
             else { S.c1 = S.c3; S.del1 = S.del3; }
             if (fabs(S.c1 - S.c2) <= 1.e-6 * S.c1) finish = true;
             else {
-                if (dsign1(s13) != dsign1(s32)) S.nev = 0;
+                if (bh_signs_differ(s13, s32)) S.nev = 0;
                 double ss1 = fabs(S.del1), s1 = pct * ss1, ss2 = fabs(S.del2), s2 = pct * ss2;
                 bool do_half = (s1 > ss2 || s2 > ss1 || S.nev == 0);
                 if (!do_half) {

@@ -452,10 +452,10 @@ BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const Del &del, int j)
             stop = S.nctrl + 1 >= 100 || c3 < dmin(n.c1, n.c2) || c3 > dmax(n.c1, n.c2);
     }
     const double s13 = n.d1 - d3, s32 = d3 - n.d2;
-    const bool neg = dsign1(d3) * dsign1(n.d1) < 0.0;
+    const bool neg = bh_signs_differ(d3, n.d1);
     const double c1 = neg ? n.c1 : c3, d1 = neg ? n.d1 : d3, c2 = neg ? c3 : n.c2, d2 = neg ? d3 : n.d2;
     if (fabs(c1 - c2) <= 1.e-6 * c1) stop = true;
-    if (dsign1(s13) != dsign1(s32)) nev = 0;
+    if (bh_signs_differ(s13, s32)) nev = 0;
     const double ss1 = fabs(d1), s1 = pct * ss1, ss2 = fabs(d2), s2 = pct * ss2;
     if (!(s1 > ss2 || s2 > ss1 || nev == 0)) stop = true;       // a Neville step comes next
     n.go = stop ? SWD_GO_STOP : neg ? SWD_GO_LEFT : SWD_GO_RIGHT;

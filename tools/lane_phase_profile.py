@@ -45,6 +45,8 @@ def main(B=131072):
     tot = v[:3].sum()
     for name, x in zip(('driver', 'period equation', 'control'), v[:3]):
         print('%-16s %5.1f %% of the lane-cycles, %7.0f cycles per evaluation' % (name, 100 * x / tot, x / v[3]))
+    print('   of the control code, Neville steps: %.1f %% of the kernel (wave-cycles in swd_neville x 64 / lane-cycles)'
+          % (100 * 64 * v[4] / tot))
     print('evaluations per search %.1f' % (v[3] / B))
     _lib.set_swd_kernel('auto')
 
