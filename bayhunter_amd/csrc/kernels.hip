@@ -168,7 +168,8 @@ struct QueueSrc {
     __device__ __forceinline__ void sphere(LdsLay &lay, int mmax, int ifunc) { swd_sphere(lay, mmax, ifunc); }
 };
 
-// 2 waves per SIMD: the search state + one Dunkin layer need ~250 VGPRs; pin the allocator there
+// 2 waves per SIMD: the search state + one Dunkin layer need 189 VGPRs (250 while polynomial coefficients
+// were kept in VGPR pairs, bh_math.h); the allocator's budget is pinned to two waves
 #ifndef BH_SWD_WAVES
 #define BH_SWD_WAVES 2            // waves per SIMD the register budget of swd_kernel is set for
 #endif
@@ -397,9 +398,8 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
     }
 }
 
-// The narrower forms carry per-team liveness through the divergent driver call and want ~310
-// registers: pinned to 2 waves per SIMD they spill ~50 dwords and are still 1.3-1.4x faster than at
-// one wave per SIMD (measured).
+// The narrower forms carry per-team liveness through the divergent driver call: ~199 registers, no
+// scratch, pinned to 2 waves per SIMD (with machine LICM on they wanted ~310 and spilled 48 bytes).
 __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team32_kernel(SwdArgs A)
 {
     swd_team_body<32>(A);
@@ -415,12 +415,13 @@ __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 // ---------------------------------------------------------------------------------- SWD, wide teams
 // 64*W lanes (W waves, one workgroup) per search: swd_team.h, "Wide teams".  Per round
-//   plan      every lane runs swd_teamw_plan in registers and keeps the trials it needs: the one it
-//             assembles a layer matrix for, the one its quad chains, and trial (lane & 63) for matching
-//   assemble  lane (j, r): matrix of layer r at trial j -> LDS, column-major           | barrier
+//   plan      control wave (wave 0): slot layout (swd_teamw_round), lane j computes slot j's (c, omega),
+//             slots and a {done, slots, mmax, llw} header -> LDS                        | barrier
+//   assemble  all waves, lane (j, r): matrix of layer r at trial j -> LDS, column-major | barrier
 //   chain     Rayleigh: quad q of wave w propagates trial 16 w + q (component i on lane i, the fifth
 //             on all four; max-reduce and re-gather by DPP quad permutes); Love: lane j   | barrier
-//   consume   every lane: values matched by (omega, c) through ballots, swd_control / swd_driver
+//   consume   control wave: lane j evaluates tree node j (swd_teamw_node), then values are matched by
+//             (omega, c) through ballots and fed to swd_control / swd_events
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad(double x)
 {

@@ -193,13 +193,16 @@ BH_DEV int swd_team_consume(SwdState &S, Nev &nv, int nt, const double *trials, 
 // Wide teams (64*W lanes per search, swd_teamw_kernel): the lowest-latency form.
 //
 // Same two ideas as above, plus:
-//   * speculation across the end of a root search.  A period's search ends with ~8 sequential
-//     Neville / bisection evaluations (one trial each; surfdisp96.f:582-673) during which all lanes
-//     but L-1 idle.  Each of those rounds also evaluates, on the idle lanes, the START of the search
-//     that follows IF the current trial turns out to be the root: the entry evaluation of the next
-//     period (or of the second solve of a group-velocity pair) at c - 1.5 dc and the first grid points
-//     of its bracketing scan (surfdisp96.f:268-271,282-294,448-470).  In the round in which the root
-//     converges the next search is therefore already bracketed (or well on its way).
+//   * the bisection tree.  A root is refined by ~13 sequential evaluations (surfdisp96.f:582-673), nine
+//     in ten of them bisections, and a bisection point is known before the value that selects it: a
+//     refinement round carries the whole tree of candidates below the pending trial, as deep as the
+//     slots allow, and consumes one value per level (swd_teamw_round, swd_teamw_node below).
+//   * speculation across the end of a root search.  Once the tree reaches the halving at which the
+//     stopping test fires, its leaves are the possible roots; behind each comes the START of the search
+//     that follows: the entry evaluation of the next period (or of the second solve of a
+//     group-velocity pair) at c - 1.5 dc and the first grid points of its bracketing scan
+//     (surfdisp96.f:268-271,282-294,448-470).  In the round in which the root converges the next search
+//     is therefore already bracketed (or well on its way).
 //   * a value is only ever consumed for the (omega, c) it was computed at: the consuming loop
 //     matches every speculative trial against what the unchanged control code (swd_control /
 //     swd_driver) asks for next, bit for bit, and stops at the first mismatch.  The prediction can be

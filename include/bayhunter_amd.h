@@ -90,10 +90,10 @@ int  bh_set_device(int device);
 size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets);
 /* Several kernels compute the same values, bit for bit:
  *   BH_SWD_LANE     one search per lane (persistent lanes, work queue): the throughput form,
- *                   ~7e6 ten-layer searches/s, ~12 ms latency
+ *                   ~1e7 ten-layer searches/s, ~11 ms latency
  *   BH_SWD_TEAM     one wave (64 lanes) per search: speculative bracketing, layer-parallel matrix
- *                   assembly, speculation across the end of a root search and on bisection steps
- *                   (swd_team.h): ~1.3 ms for up to ~1000 ten-layer searches
+ *                   assembly, the bisection tree of a refinement and the start of the next root
+ *                   search evaluated ahead (swd_team.h): ~1.0 ms for up to ~1000 ten-layer searches
  *   TEAM128/256/512 2, 4, 8 waves per search: deeper speculation for deep models / few searches
  *   TEAM32/16/8     2, 4, 8 searches per wave: less speculation, more searches resident
  * BH_SWD_AUTO (default) picks by a measured latency / saturation-rate table on searches per call,
