@@ -21,7 +21,7 @@ Bounds derived from that criterion:
 two results are the sum of two brackets apart: 2e-6 c in phase velocity and 4e-4 (U/c) U in group
 velocity -- relative to U that is unbounded where the finite-difference denominator nearly vanishes, i.e.
 at the anomalous points of low-velocity-zone dispersion curves where U >> c.  Random campaigns over
-6.7 M searches incl. higher modes, earth flattening, water layers and irregular periods --
+10.8 M searches incl. higher modes, earth flattening, water layers and irregular periods --
 tests/scenarios/kernel_fuzz.py, profiles/r02_kernel_fuzz.txt -- saw at most 1.99e-6 in phase velocity,
 and 2.1e-4 .. 1.5e-2 in group velocity depending on whether a seed hits such a point (3-layer LVZ model,
 60 periods); the test sets below stay at 1.05e-6 and 2.1e-4.  All kernel forms agree with each other bit
