@@ -286,14 +286,14 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     const long cus = resident > 0 ? resident / 8 : 256;
     struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
     static const Form forms[8] = {
-        {0,   {4.44, 6.07, 11.1, 15.6, 31.1}, {24731, 15259, 8238, 5530, 3422}},    // lane kernel
-        {8,   {2.52, 3.6, 6.17, 7.1, 12.3},   {6024, 4035, 2351, 1581, 748}},
-        {16,  {2.11, 2.64, 5.01, 5.99, 10.6}, {3682, 2677, 1469, 1152, 942}},
-        {32,  {1.67, 1.95, 2.87, 3.98, 8.94}, {2395, 1882, 1260, 855, 673}},
-        {64,  {0.62, 0.62, 0.97, 1.59, 3.63}, {3309, 2919, 1857, 1118, 905}},
-        {128, {0.52, 0.52, 0.86, 1.13, 2.22}, {1916, 1588, 951, 681, 465}},
-        {256, {0.52, 0.52, 0.71, 0.9, 1.54},  {1069, 914, 664, 499, 379}},
-        {512, {0.56, 0.56, 0.76, 0.88, 1.55}, {543, 478, 364, 309, 223}},
+        {0,   {3.66, 5.37, 9.93, 14.1, 30.4}, {29257, 16487, 8629, 5815, 3508}},    // lane kernel
+        {8,   {2.28, 3.32, 5.78, 6.73, 12.1}, {6674, 4352, 2469, 1652, 781}},
+        {16,  {1.87, 2.49, 4.72, 5.77, 9.82}, {3986, 2895, 1536, 1196, 978}},
+        {32,  {1.49, 1.89, 2.75, 3.89, 8.75}, {2563, 1994, 1306, 884, 687}},
+        {64,  {0.61, 0.62, 0.98, 1.6, 3.7},   {3366, 2953, 1710, 1032, 836}},
+        {128, {0.51, 0.51, 0.86, 1.1, 2.2},   {1959, 1624, 961, 692, 476}},
+        {256, {0.43, 0.43, 0.68, 0.87, 1.5},  {1241, 1089, 680, 518, 397}},
+        {512, {0.47, 0.47, 0.65, 0.83, 1.51}, {645, 575, 414, 324, 233}},
     };
     const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
     bool team = false;

@@ -211,7 +211,7 @@ BH_DEV int swd_team_consume(SwdState &S, Nev &nv, int nt, const double *trials, 
 //     four) with DPP quad permutes instead of LDS shuffles, matrices stored column-major so that a
 //     lane's column is one 48-byte run (kernels.hip).
 // Trials of a round are numbered 0..nt-1; trial j has its own (c, omega).
-enum { SWD_TEAMW_NT = 32 };       // max trials per round
+enum { SWD_TEAMW_NT = 64 };       // max trials per round (one per lane of the control wave)
 #ifndef SWD_TEAMW_MIDROOM
 #define SWD_TEAMW_MIDROOM 24   // scan slots from which on the cell midpoints ride along (replay: 16 and 24 within 1 %)
 #endif
@@ -251,7 +251,7 @@ struct TeamwScan {                // an entry evaluation (optional) and the scan
 };
 struct TeamwRound {
     int nt;                       // slots in use
-    int nhalf;                    // bisection candidates in slots 1 .. nhalf (0, 2, 6, 14 or 30): the
+    int nhalf;                    // bisection candidates in slots 1 .. nhalf (0, 2, 6, 14, 30 or 62): the
                                   // tree in level order, left (c1 side) to right
     int ngrp;                     // scan groups in use (0..2); g1 follows g0
     TeamwScan g0, g1;
@@ -437,10 +437,10 @@ BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const Del &del, int j)
     double c3 = S.ceval;
     // values of the ancestors (level m: slot ((j + 1) >> (l - m)) - 1), fetched together: the walk
     // below is then arithmetic only
-    double da[4];
-    for (int m = 0; m < 4; m++) da[m] = del(m < l ? ((j + 1) >> (l - m)) - 1 : 0);
+    double da[5];
+    for (int m = 0; m < 5; m++) da[m] = del(m < l ? ((j + 1) >> (l - m)) - 1 : 0);
     const double d3 = del(j);
-    for (int m = 0; m < 4; m++) {
+    for (int m = 0; m < 5; m++) {
         if (m < l) {
             const int bit = (pth >> (l - 1 - m)) & 1;
             if (bit) { n.c1 = c3; n.d1 = da[m]; } else { n.c2 = c3; n.d2 = da[m]; }
