@@ -154,6 +154,11 @@ _SIGS = {
     "bh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "bh_set_device": (C.c_int, [C.c_int]),
     "bh_swd_set_kernel": (C.c_int, [C.c_int]),
+    "bh_swd_last_form": (C.c_int, []),
+    "bh_rf_active_frequencies": (C.c_int, [C.POINTER(RfParams)]),
+    "surfdisp96_": (None, [_vp] * 13),
+    "synrf_cwrap": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                              C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bh_swd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(SwdTarget)]),
     "bh_swd_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                C.POINTER(SwdTarget), _vp, _vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),

@@ -74,11 +74,17 @@ def _server_alive(pid):
 def _serve(shared, backend_factory, swd, rf):
     S = shared
     S['server_pid'].value = os.getpid()
+    # A server that could not create its back end, or whose launch failed, ends with a non-zero exit
+    # code (a supervisor / `_proc.exitcode` must not see a clean exit); KeyboardInterrupt and SystemExit
+    # are reported to the waiting clients and then re-raised, not swallowed.
     try:
         run = backend_factory(swd, rf)
-    except BaseException:
+    except Exception:
         _fail(S, 'broker back end could not be created:\n' + traceback.format_exc())
-        return
+        sys.exit(1)
+    except BaseException:
+        _fail(S, 'broker server interrupted while creating its back end:\n' + traceback.format_exc())
+        raise
     model = np.frombuffer(S['model'], dtype=np.float64).reshape(S['n'], 4, S['Lmax'])
     rows = np.frombuffer(S['rows'], dtype=np.float64).reshape(S['n'], S['row'])
     flags = np.frombuffer(S['flags'], dtype=np.int32).reshape(S['n'], S['nflags'])
@@ -107,12 +113,16 @@ def _serve(shared, backend_factory, swd, rf):
             out, err = run(m[:, 0], m[:, 1], m[:, 2], m[:, 3], nlay[pending].copy())
             rows[pending] = out
             flags[pending] = err
-        except BaseException:
+        except Exception:
             # A failed launch (HIP error, out of memory, bad shapes) ends the server: a process that
             # has touched the GPU is never restarted in place.  Clients raise BrokerError; recovery
             # is a fresh ForwardBroker started from a process that has not used the GPU.
             _fail(S, 'broker launch of %d models failed:\n' % pending.size + traceback.format_exc())
-            return
+            sys.exit(1)
+        except BaseException:
+            _fail(S, 'broker server interrupted during a launch of %d models:\n' % pending.size
+                  + traceback.format_exc())
+            raise
         stats[0] += 1
         stats[1] += pending.size
         stats[2] += time.perf_counter() - t0
@@ -147,6 +157,7 @@ class ForwardBroker(object):
             failed=ctx.Value('i', 0), server_pid=ctx.Value('i', 0), errtext=ctx.RawArray('c', 4096))
         self._factory = backend_factory
         self._proc = None
+        self.exitcode = None
 
     def start(self):
         """Fork the server.  Nothing in this process may have touched the GPU before: a forked child
@@ -190,6 +201,7 @@ class ForwardBroker(object):
             self.shared['stop'].value = 1
             self.shared['wake'].release()
             self._proc.join(timeout=30)
+            self.exitcode = self._proc.exitcode      # 0: stopped on request; non-zero: the server failed
             self._proc = None
 
 

@@ -26,8 +26,10 @@ namespace bh {
 // polynomial coefficients in VGPR pairs and, the kernels being at their register limit, copies each
 // into the accumulator before a two-address v_fmac_f64 (a v_mov_b64 per step: 50 of the ~450 vector
 // instructions of a layer step of swd_kernel).  The three-address form with the coefficient as a scalar
-// operand needs neither the copy nor the VGPRs.  K MUST be a constant (an "s" operand is read from one
-// lane).  (-DBH_NO_FMA_K: the plain builtin, for A/B measurements.)
+// operand needs neither the copy nor the VGPRs.  An "s" operand is read from one lane, so the scalar form
+// is only taken when K is a compile-time constant after inlining (__builtin_constant_p, resolved late
+// through llvm.is.constant); anything else gets the plain builtin.  (-DBH_NO_FMA_K: always the plain
+// builtin, for A/B measurements and the bit-parity matrix.)
 #if defined(BH_HOSTSIM)
 BH_DEV double bh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 BH_DEV double bh_fma_k(double a, double b, double k) { return __builtin_fma(a, b, k); }
@@ -40,6 +42,7 @@ BH_DEV double bh_fma_k(double a, double b, double k) { return __builtin_fma(a, b
 #else
 BH_DEV double bh_fma_k(double a, double b, double k)
 {
+    if (!__builtin_constant_p(k)) return __builtin_fma(a, b, k);
     double r;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
     return r;

@@ -165,6 +165,7 @@ int release_queue_slot(int i, hipStream_t stream)
 
 // kernel choice of bh_swd_batch: process-wide default (bh_swd_set_kernel), read once per call
 std::atomic<int> g_swd_mode{BH_SWD_AUTO};
+thread_local int g_last_form = -1;    // what the last bh_swd_batch of this thread launched (bh_swd_last_form)
 
 long team_threshold()
 {
@@ -325,10 +326,13 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     if (team && width < 64) team_resident = narrow_resident(width);
     hipError_t le = team ? bh::launch_swd_team(A, width, team_resident, (hipStream_t)stream)
                          : bh::launch_swd(A, resident, (hipStream_t)stream);
+    g_last_form = team ? width : 0;
     rc = release_queue_slot(slot, (hipStream_t)stream);    // also after a failed launch: the slot is free
     if (le != hipSuccess) return fail_hip(le, "dispersion kernel launch");
     return rc;
 }
+
+int bh_swd_last_form(void) { return g_last_form; }
 
 int bh_swd_order_keys(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vs,
                       double longest_period, int by_length, int *keys, void *stream)
@@ -346,6 +350,15 @@ int bh_swd_order_keys(int B, int Lmax, int model_stride, const int *nlay, const 
 }
 
 size_t bh_rf_workspace_bytes(int, int, const bh_rf_params *) { return 0; }
+
+int bh_rf_active_frequencies(const bh_rf_params *par)
+{
+    if (!par || par->nsamp < 8 || par->nsamp > 4096 || !(par->gauss > 0) || !(par->fsamp > 0)) return 0;
+    bh::RfLaunch P;
+    std::memset(&P, 0, sizeof(P));
+    bh::rf_fill_launch(P, par->p, par->gauss, par->nsamp, par->fsamp, par->tshift, par->nsv, par->waveno, par->nout);
+    return P.nact;
+}
 
 static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vp,
                             const double *vs, const double *rho, const double *qp, const double *qs,
@@ -558,6 +571,40 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
                          hipMemcpyDeviceToHost));
     }
     return BH_OK;
+}
+
+// ---- the reference's own FFI symbols ------------------------------------------------------------
+// What f2py binds for `subroutine surfdisp96` (surfdisp96.f:55-56: every argument by reference, no
+// return value) and what rfmini.pyx:74-114 binds (wrap.cpp:57-63: returns 1).  Neither has an error
+// channel beyond `err`: when the library itself fails (no device, limits) the message goes to stderr
+// and the caller sees the reference's failure convention -- err != 0 (SurfDisp.run_model then returns
+// (nan, nan), surf96_modsw.py:119-126) or a NaN trace (rejected by Targets.py:204-214).
+void surfdisp96_(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                 const int *nlayer, const int *iflsph, const int *iwave, const int *mode, const int *igr,
+                 const int *kmax, const double *t, double *cg, int *err)
+{
+    int rc = (nlayer && iflsph && iwave && mode && igr && kmax && err)
+                 ? bh_surfdisp96(thkm, vpm, vsm, rhom, *nlayer, *iflsph, *iwave, *mode, *igr, *kmax, t, cg, err)
+                 : fail_arg("NULL pointer");
+    if (rc != BH_OK) {
+        std::fprintf(stderr, "libbayhunter_amd: surfdisp96_ failed (%d): %s\n", rc, g_err.c_str());
+        if (err) *err = 100 + rc;
+    }
+}
+
+int synrf_cwrap(int nsamp, double fsamp, double tshift, double p, double a, double nsv, double sigma,
+                int waveno, int nlay, double *z, double *vp, double *vs, double *rh, double *qp, double *qs,
+                double *fz, double *fr, double *rf)
+{
+    int rc = bh_synrf(nsamp, fsamp, tshift, p, a, nsv, sigma, waveno, nlay, z, vp, vs, rh, qp, qs, fz, fr, rf);
+    if (rc == BH_OK) return 1;
+    std::fprintf(stderr, "libbayhunter_amd: synrf_cwrap failed (%d): %s\n", rc, g_err.c_str());
+    for (int i = 0; i < nsamp && nsamp <= 4096; i++) {
+        if (rf) rf[i] = std::nan("");
+        if (fz) fz[i] = std::nan("");
+        if (fr) fr[i] = std::nan("");
+    }
+    return 0;
 }
 
 int bh_selftest_division(long n, unsigned seed, int max_exp, long *mismatches)

@@ -894,8 +894,10 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         for (int idx = tid; idx < Mb * n; idx += RF_T) {
             int m = idx / n, i = idx - m * n;
             const double *Sm = S + (long)m * pm;
-            A.out_fr[(long)(b0 + m) * n + i] = P.qn * Sm[2 * rf_swz(i)];
-            A.out_fz[(long)(b0 + m) * n + i] = P.qn * Sm[2 * rf_swz(i) + 1];
+            const int nl = A.nlay[b0 + m];
+            const bool bad_depth = nl < 1 || nl > L;   // as for the RF row: never a trace of a truncated model
+            A.out_fr[(long)(b0 + m) * n + i] = bad_depth ? __builtin_nan("") : P.qn * Sm[2 * rf_swz(i)];
+            A.out_fz[(long)(b0 + m) * n + i] = bad_depth ? __builtin_nan("") : P.qn * Sm[2 * rf_swz(i) + 1];
         }
     }
 }

@@ -33,7 +33,10 @@ inline void rf_fill_launch(RfLaunch &P, double p, double gauss, int nsamp, doubl
     // below RF_WEIGHT_CUTOFF of its value at w = 0 are set to zero instead of being computed: their
     // contribution to a sample is cutoff x |R/Z| (the deconvolved spectral ratio, O(1..1e3) for a
     // layered model with attenuation), i.e. <= 1e-16 of the trace's scale -- five orders below the
-    // parity tolerance of 1e-10 even for a ratio of 1e4.  a = 1, 5 Hz, nsamp 512: 213 of 257
+    // parity tolerance of 1e-10 even for a ratio of 1e4 (summed over the ~44 dropped bins: 4e-15).  Checked
+    // on the models most likely to break it -- thin very slow surface layer, Q down to 5, a = 0.8..1.2 --
+    // against the oracle, which computes every bin: <= 2.9e-15 (tests/rf_extreme.py, test_hostsim.py and the
+    // GPU tier).  a = 1, 5 Hz, nsamp 512: 213 of 257
     // frequencies are computed (5 instead of 6 passes of a 256-thread workgroup over 6 models; the
     // round-1 cutoff of 1e-24 kept 243); a >= 1.21: all of them.
     const double wcut = 2.0 * gauss * std::sqrt(std::log(1.0 / RF_WEIGHT_CUTOFF));

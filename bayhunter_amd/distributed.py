@@ -47,9 +47,15 @@ def gather_rows(local, n_total, group=None):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
 
+def _global(group, r):
+    """Rank r of `group` as the world rank that send / irecv / gather address."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
 def gather_rows_to_root(local, n_total, dst=0, group=None):
     """Rank `dst` gets the full [n_total, ...] tensor (blocks in shard_range order), every other
-    rank returns None.  Point-to-point: each rank sends its own block, unpadded, once."""
+    rank returns None.  Point-to-point: each rank sends its own block, unpadded, once.  `dst` and
+    the shard order are ranks WITHIN `group` (a sub-group's ranks need not be 0..n-1 of the world)."""
     if not dist.is_initialized():
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -59,7 +65,7 @@ def gather_rows_to_root(local, n_total, dst=0, group=None):
     local = local.contiguous()
     if rank != dst:
         if sizes[rank]:
-            dist.send(local, dst=dst, group=group)
+            dist.send(local, dst=_global(group, dst), group=group)
         return None
     full = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     lo = 0
@@ -68,7 +74,7 @@ def gather_rows_to_root(local, n_total, dst=0, group=None):
         if r == dst:
             full[lo:lo + n] = local
         elif n:
-            reqs.append(dist.irecv(full[lo:lo + n], src=r, group=group))     # all peers at once
+            reqs.append(dist.irecv(full[lo:lo + n], src=_global(group, r), group=group))     # all peers at once
         lo += n
     for q in reqs:
         q.wait()
@@ -77,17 +83,18 @@ def gather_rows_to_root(local, n_total, dst=0, group=None):
 
 def gather_ragged_to_root(local, dst=0, group=None):
     """Row blocks of different, a-priori unknown length (e.g. thinned chains): the root gets the list
-    of every rank's block (rank order), the others None.  Lengths travel first (one int64 each)."""
+    of every rank's block (rank order), the others None.  Lengths travel first (one int64 each).
+    `dst` is a rank within `group`."""
     if not dist.is_initialized():
         return [local]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(n) for _ in range(world)] if rank == dst else None
-    dist.gather(n, counts, dst=dst, group=group)
+    dist.gather(n, counts, dst=_global(group, dst), group=group)
     local = local.contiguous()
     if rank != dst:
         if local.shape[0]:
-            dist.send(local, dst=dst, group=group)
+            dist.send(local, dst=_global(group, dst), group=group)
         return None
     out, reqs = [], []
     for r in range(world):
@@ -97,7 +104,7 @@ def gather_ragged_to_root(local, dst=0, group=None):
             continue
         buf = torch.empty((k,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         if k:
-            reqs.append(dist.irecv(buf, src=r, group=group))
+            reqs.append(dist.irecv(buf, src=_global(group, r), group=group))
         out.append(buf)
     for q in reqs:
         q.wait()

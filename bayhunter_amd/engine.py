@@ -256,7 +256,11 @@ class ForwardEngine(object):
                         y = ((f1 - f0) / tb['dx']) * tb['xm'] + f0
                         out[:, sl] = torch.where(tb['last'], f[:, -1:].expand(-1, y.shape[1]), y)
             else:
-                err.zero_()
+                # no dispersion kernel to raise BH_MODEL_BAD_DEPTH: the receiver-function kernel NaNs the
+                # row of a model whose nlay is outside 1..Lmax, the flag is set here
+                with torch.cuda.stream(st):
+                    err.zero_()
+                    err[:, 0] = torch.where((nlay < 1) | (nlay > Lmax), 2, 0).to(torch.int32)
             rsp = sp if side is None else C.c_void_p(side.cuda_stream)
             for rp in self._rfp:
                 _lib.check(self.lib.bh_rf_batch(

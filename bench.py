@@ -1,24 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- forward evaluations per second of the BayHunter likelihood hot path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched through
-torch.distributed.run, one rank per GPU) prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
+
+  * N = 1: one process, one GPU.
+  * N > 1 started through `torch.distributed.run` (WORLD_SIZE/RANK/LOCAL_RANK in the environment):
+    this process is one rank; WORLD_SIZE must equal --gpus.
+  * N > 1 started as a plain `python bench.py --gpus N`: this process touches neither torch nor the
+    GPU; it starts N fresh rank processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), waits for them
+    and relays rank 0's line.  (Never an exec of a process that has initialised the GPU.)
+  Every rank binds LOCAL_RANK to its own device and fails when fewer devices than ranks are visible
+  (stacking ranks on one device is allowed only with BH_DIST_BACKEND=gloo, the one-GPU rehearsal).
+  Rank 0 checks that the process group has --gpus ranks, collects every rank's device index / UUID
+  and step time, and reports `n_gpus`, `ranks_seen`, `devices_seen`, `per_rank_ms_per_step`.
 
 A "step" is one pass of the hot path over one batch of synthetic layered models that is already
 resident in HBM: all dispersion targets of the workload (swd kernel) + the receiver function
 (rf kernel) for every model of the rank's shard.  One "evaluation" = all targets of one model
-(SURVEY.md section 8d).  Chains are independent, so ranks shard the models with no data-path
-collective (weak scaling: the per-GPU batch is fixed); the only collectives are the timing barrier
-and the MAX over ranks.
+(SURVEY.md section 8d).  Chains are independent (reference src/mcmcOptimizer.py:238-252), so ranks
+shard the models with no data-path collective (weak scaling: the per-GPU batch is fixed); the only
+collectives are the timing barrier, the MAX over ranks and the gather of the ranks' identities.
 
 Workloads (BASELINE.json):
-  joint10  (default; the configuration the metric "forward evals/sec (SWD+RF, 10-layer)" is quoted
+  joint10  (headline; the configuration the metric "forward evals/sec (SWD+RF, 10-layer)" is quoted
            on) Rayleigh phase velocity at 21 periods + P receiver function (201 samples @ 5 Hz,
            nsamp 512), 10-layer models
   cfg2     Rayleigh phase only, 5 layers, 20 periods, 1024 models
   cfg3     Rayleigh+Love x phase+group, 10 layers, 40 periods, 8192 models
   cfg4     Rayleigh phase (21) + P-RF, 15 layers, 64 models per GPU
   cfg5     ragged 2..31 layers, Rayleigh phase (21) + P-RF
+The default run times the headline and then each of cfg2..cfg5 for a bounded number of steps
+(`configs` in the line: value, ms_per_step, kernel form, roofline, cpu_baseline per config).
 """
 import argparse
 import json
@@ -44,7 +56,9 @@ WORKLOADS = {
     'cfg4':    dict(L=15, refs=['rdispph'], P=21, rf=True, B=64, cfg=4),
     'cfg5':    dict(L=(2, 31), refs=['rdispph'], P=21, rf=True, B=8192, cfg=5),
 }
+CONFIG_ORDER = ['cfg2', 'cfg3', 'cfg4', 'cfg5']
 REF_TAGS = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
+RF_NSAMP, RF_NOUT = 512, 201
 
 
 def make_models(wl, B, rank):
@@ -57,11 +71,28 @@ def algorithmic_bytes(wl, Lmean):
     kernel (each kernel reads the model once)."""
     model = 32.0 * Lmean + 4
     swd = model + sum(8.0 * wl['P'] + 4 for _ in wl['refs'])
-    rf = (model + 8.0 * 201) if wl['rf'] else 0.0
+    rf = (model + 8.0 * RF_NOUT) if wl['rf'] else 0.0
     return swd, rf
 
 
+def rf_flops(Lmean, nfreq_computed):
+    """SURVEY.md 8(d) receiver-function formula with the frequencies the kernel actually computes
+    (`nact`, bh_rf_active_frequencies: bins whose Gauss-filter weight is below 3e-19 are zero-filled)
+    in place of nfreq = 257."""
+    return nfreq_computed * (Lmean - 1) * 500 + Lmean * 300 + nfreq_computed * 60 + 5 * RF_NSAMP * 9
+
+
 # ------------------------------------------------------------------------------------ CPU baseline
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except (IOError, OSError):
+        pass
+    return 'unknown'
+
+
 def _cpu_worker(args):
     wl_name, n, seed, use_ref = args
     from oracle import pyoracle as po
@@ -79,9 +110,10 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(wl_name, per_core=None):
+def cpu_baseline(wl_name, seconds):
     """Reference native code (oracle/_ref, kind "reference") or the C restatement (kind "port")
-    on all host cores of this box, one process per core, on a bounded sample of the same workload.
+    on the host cores of this box, one process per core, on a bounded sample of the same workload
+    (`seconds` of work per core at the reference's measured single-core rates).
     Runs in a child process tree that never touches the GPU."""
     import multiprocessing as mp
     from oracle import pyoracle as po
@@ -91,11 +123,9 @@ def cpu_baseline(wl_name, per_core=None):
     # a one-GPU box exposes 256 logical CPUs but its CPU share is 16: more workers only oversubscribe
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get('BH_CPU_WORKERS', 16)))
     wl = WORKLOADS[wl_name]
-    if per_core is None:
-        # ~10 s per core at the reference's measured single-core rates
-        cost = (len(wl['refs']) * wl['P'] / 21.0 * 0.5e-3 + (0.85e-3 if wl['rf'] else 0)) * \
-               (np.mean(wl['L']) / 10.0)
-        per_core = int(max(64, min(20000, 8.0 / cost)))
+    cost = (len(wl['refs']) * wl['P'] / 21.0 * 0.5e-3 + (0.85e-3 if wl['rf'] else 0)) * \
+           (np.mean(wl['L']) / 10.0)
+    per_core = int(max(64, min(60000, seconds / cost)))
     ctx = mp.get_context('fork')
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -103,11 +133,12 @@ def cpu_baseline(wl_name, per_core=None):
     wall = time.perf_counter() - t0
     n = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
-    return {"value": n / busy, "unit": "evals/s", "cores": cores,
+    return {"value": n / busy, "unit": "evals/s", "cores": cores, "cpu": cpu_model_name(),
+            "logical_cpus_visible": len(os.sched_getaffinity(0)),
             "kind": "reference" if use_ref else "port",
             "per_core": n / sum(r[1] for r in res),
-            "sample": "%d models (%d per core, %d processes), workload %s, %.1f s wall"
-                      % (n, per_core, cores, wl_name, wall)}
+            "sample": "%d models (%d per core, %d processes), workload %s, %.1f s of solver time per core, "
+                      "%.1f s wall incl. model generation" % (n, per_core, cores, wl_name, busy, wall)}
 
 
 def measured_traffic(kernel, workload, B, live_ms, lib_hash):
@@ -127,8 +158,9 @@ def measured_traffic(kernel, workload, B, live_ms, lib_hash):
         cfg = d.get('config', '')
         wl_ok = ('--workload ' + workload) in cfg or (workload == 'joint10' and '--workload' not in cfg)
         b_ok = ('--batch %d' % B) in cfg or ('--batch' not in cfg and B == WORKLOADS[workload]['B'])
-        if wl_ok and b_ok and kernel in d.get('kernels', {}):
-            best, name = dict(d['kernels'][kernel], lib_src_hash=d.get('lib_src_hash', ''), git_sha=d.get('git_sha', '')), f
+        for k, rec in d.get('kernels', {}).items():
+            if wl_ok and b_ok and kernel in k:
+                best, name = dict(rec, lib_src_hash=d.get('lib_src_hash', ''), git_sha=d.get('git_sha', '')), f
     if best is None:
         return None, 'no PMC record for this configuration under profiles/'
     name = os.path.relpath(name, ROOT)
@@ -156,7 +188,45 @@ N_DLTAR = {
 }
 
 
-# ----------------------------------------------------------------------------------------- main
+# --------------------------------------------------------------------------------- rank launcher
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script
+    from a parent that has imported neither torch nor the HIP library, wait, relay rank 0's line."""
+    import socket
+    n = args.gpus
+    with socket.socket() as s:                       # a free rendezvous port on the loopback
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                MASTER_PORT=str(port), BH_BENCH_LAUNCHER='bench.py')
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                                  # the exact PID this launcher started
+            rcs.append(p.wait())
+    if any(rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write('bench.py launcher: rank exit codes %s\n' % rcs)
+        sys.stdout.write(out0)
+        sys.exit(1)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+
+
+# ------------------------------------------------------------------------------------ chain pool
 def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
     """End-to-end sampler on top of the timed path (not part of `value`): a lock-step pool of
     chains on the tutorial inversion (Rayleigh phase + P-RF, observed data in
@@ -185,91 +255,90 @@ def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
         return {"value": None, "error": repr(e)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='joint10', choices=sorted(WORKLOADS))
-    ap.add_argument('--batch', type=int, default=None, help='models per GPU per step')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-only', action='store_true')
-    ap.add_argument('--no-chain-pool', action='store_true')
-    args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
+# -------------------------------------------------------------------------------- one workload
+class Ranks(object):
+    """The process group as the timed region sees it (a no-op for one rank)."""
 
-    if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.workload)))
-        return
+    def __init__(self, world, backend, device_index):
+        self.world, self.backend, self.dev = world, backend, device_index
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.backend == 'nccl':
+                dist.barrier(device_ids=[self.dev])
+            else:
+                dist.barrier()
 
-    # CPU baseline first, in a child that never initialises the GPU (rank 0, N=1 only)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only',
-                            '--workload', args.workload], capture_output=True, text=True)
-        if r.returncode == 0:
-            cpu = json.loads(r.stdout.strip().splitlines()[-1])
-        else:
-            sys.stderr.write('cpu baseline failed: %s\n' % r.stderr[-2000:])
+    def max(self, value):
+        from bayhunter_amd.distributed import max_over_ranks
+        return max_over_ranks(value, device='cuda' if self.backend == 'nccl' else 'cpu')
 
+    def all_floats(self, value):
+        if self.world == 1:
+            return [float(value)]
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([value], dtype=torch.float64, device='cuda' if self.backend == 'nccl' else 'cpu')
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t)
+        return [float(p.item()) for p in parts]
+
+
+def run_workload(name, B, rank, ranks, steps, warmup, serial=False, budget_s=None):
+    """Upload one batch of `name`, time `steps` passes (or, with budget_s, as many as fit that many
+    seconds after a probe), then the per-kernel durations with events on the launch stream."""
     import torch
-    import torch.distributed as dist
-    from bayhunter_amd.distributed import max_over_ranks
+    from bayhunter_amd import _lib as bhlib
     from bayhunter_amd.engine import ForwardEngine, RfSpec, SwdSpec
-
-    # BH_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 code path on a
-    # one-GPU box (ranks then share device 0); the driver runs one rank per GPU over RCCL ("nccl")
-    backend = os.environ.get('BH_DIST_BACKEND', 'nccl')
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend)
-
-    B = args.batch or wl['B']
+    wl = WORKLOADS[name]
     per = np.linspace(1, 41, wl['P'])
     H, VP, VS, RHO, nl = make_models(wl, B, rank)
     swd_specs = [SwdSpec(r, per) for r in wl['refs']]
-    rf_specs = [RfSpec('prf', np.linspace(-5, 35, 201))] if wl['rf'] else []
-    eng_swd = ForwardEngine(swd=swd_specs, rf=rf_specs)            # the product path: one engine
+    rf_specs = [RfSpec('prf', np.linspace(-5, 35, RF_NOUT))] if wl['rf'] else []
+    eng = ForwardEngine(swd=swd_specs, rf=rf_specs)               # the product path: one engine
     eng_only_swd = ForwardEngine(swd=swd_specs)                     # per-kernel timing only
     eng_only_rf = ForwardEngine(rf=rf_specs) if rf_specs else None
     if eng_only_rf:                                                 # same output row layout
-        eng_only_rf._rfp[0].out_off = eng_swd._rfp[0].out_off
-        eng_only_rf.row = eng_swd.row
-    eng_only_swd.row = eng_swd.row
-    dmodels = eng_swd.upload(H, VP, VS, RHO, nl)                       # inputs resident in HBM
-    out, err = eng_swd.alloc_out(B)
+        eng_only_rf._rfp[0].out_off = eng._rfp[0].out_off
+        eng_only_rf.row = eng.row
+    eng_only_swd.row = eng.row
+    dmodels = eng.upload(H, VP, VS, RHO, nl)                       # inputs resident in HBM
+    out, err = eng.alloc_out(B)
+    if serial:
+        eng.overlap = False       # profiling passes: rf_kernel behind swd_kernel on one stream
 
     def step():
         # a sampler brings new models every step: the processing order (a sort by depth and S travel
         # time, engine.reorder) is part of the step, not of the upload
-        eng_swd.run(eng_swd.reorder(dmodels.packed, dmodels.nlay), out=out, err=err)
+        eng.run(eng.reorder(dmodels.packed, dmodels.nlay, depth=dmodels.depth), out=out, err=err)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if budget_s is not None:          # bounded configs: the step count from a short probe, same on all ranks
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        est = ranks.max((time.perf_counter() - t0) / 3)
+        steps = int(max(5, min(400, budget_s / max(est, 1e-5))))
+    ranks.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dt_local = time.perf_counter() - t0
+    ranks.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt, device='cuda' if backend == 'nccl' else 'cpu')
+    dt = ranks.max(time.perf_counter() - t0)
+    form = bhlib.load().bh_swd_last_form()
 
     # per-kernel durations for the roofline: the same launches, serialised on one stream, bracketed
     # by events on that stream (in the timed steps above rf_kernel overlaps the tail of swd_kernel)
-    nk = min(args.steps, 5)
+    nk = min(steps, 5)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nk)]
-    eng_swd.overlap = False
     eng_only_swd.run(dmodels, out=out, err=err)         # (one untimed pass: first-use costs of these two
     if eng_only_rf:                                      # engines, e.g. lazily loaded fill kernels)
         eng_only_rf.run(dmodels, out=out, err=err)
@@ -282,69 +351,237 @@ def main():
             eng_only_rf.run(dmodels, out=out, err=err)
         ev[i][2].record()
     torch.cuda.synchronize()
-    eng_swd.overlap = True
     ms_swd = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_rf = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if eng_only_rf else 0.0
-    nerr = int(err.sum().item())
+    nact = int(bhlib.load().bh_rf_active_frequencies(eng._rfp[0])) if eng_only_rf else 0
+    return dict(name=name, B=B, steps=steps, dt=dt, dt_local=dt_local, ms_swd=ms_swd, ms_rf=ms_rf,
+                nerr=int(err.sum().item()), form=form, nact=nact)
+
+
+def form_name(form):
+    return 'swd_kernel (one search per lane)' if form == 0 else 'swd_team kernel, %d lanes per search' % form
+
+
+def rooflines(r, lib_hash):
+    """roofline of the dominant kernel of a workload + the same figures for both kernels."""
+    wl = WORKLOADS[r['name']]
+    counts, Lmean = N_DLTAR[r['name']]
+    B = r['B']
+    bytes_swd, bytes_rf = algorithmic_bytes(wl, Lmean)
+    flop_swd = sum(counts[k] * (Lmean - 1) * (F_RAYLEIGH if REF_TAGS[k][0] == 2 else F_LOVE) for k in wl['refs'])
+    flop_rf = rf_flops(Lmean, r['nact']) if wl['rf'] else 0.0
+
+    def one(kernel, ms, flop, nbytes, extra):
+        tflops = flop * B / (ms * 1e-3) / 1e12
+        gbs = nbytes * B / (ms * 1e-3) / 1e9
+        pmc, note = measured_traffic(kernel, r['name'], B, ms, lib_hash)
+        pmc = pmc or {}
+        d = {"kernel": kernel, "bound": "fp64_valu", "achieved": tflops, "peak": FP64_PEAK_TFLOPS,
+             "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": pmc.get('hbm_bytes'),
+             "kernel_ms": ms, "algorithmic_flop_per_launch": flop * B,
+             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": nbytes * B,
+                     "traffic_bytes_per_launch_pmc": pmc.get('hbm_bytes')},
+             "valu_pipes_busy_pmc": pmc.get('valu_busy'),
+             "lane_utilisation_pmc": pmc.get('lane_utilisation'),
+             # share of the VALU issue slots doing lane work: what is left to gain by scheduling
+             "issue_frac_pmc": (pmc['valu_busy'] * pmc['lane_utilisation']
+                                if pmc.get('valu_busy') and pmc.get('lane_utilisation') else None),
+             "pmc_source": note}
+        d.update(extra)
+        return d
+
+    swd = one('swd_kernel', r['ms_swd'], flop_swd, bytes_swd,
+              {"n_dltar_per_eval": counts, "form": form_name(r['form']),
+               "flop_model": "N_dltar x (L-1) x 190 (Rayleigh) / 30 (Love), FMA = 2"})
+    rf = one('rf_kernel', r['ms_rf'], flop_rf, bytes_rf,
+             {"frequencies_computed": r['nact'], "frequencies_total": RF_NSAMP // 2 + 1,
+              "flop_model": "nact x (L-1) x 500 + L x 300 + nact x 60 + 5 nsamp log2 nsamp (SURVEY 8d with "
+                            "the computed frequencies)"}) if wl['rf'] else None
+    dom = swd if (rf is None or r['ms_swd'] >= r['ms_rf']) else rf
+    return dom, swd, rf, flop_swd + flop_rf
+
+
+def workload_label(name, B):
+    wl = WORKLOADS[name]
+    return "%s: %s%s, %s layers, %d periods, %d models/GPU/step" % (
+        name, '+'.join(wl['refs']), '+prf(201 samples, nsamp 512)' if wl['rf'] else '', str(wl['L']), wl['P'], B)
+
+
+# ----------------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='joint10', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='models per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', default=None, metavar='WORKLOADS',
+                    help='(internal) comma separated workload=seconds list; prints a JSON dict')
+    ap.add_argument('--no-chain-pool', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the cfg2..cfg5 lines after the headline')
+    ap.add_argument('--probe-ranks', action='store_true',
+                    help='(test hook) rendezvous only, on the CPU over gloo: prints who showed up, no GPU work')
+    ap.add_argument('--serial', action='store_true',
+                    help='profiling: rf_kernel behind swd_kernel on one stream (no back-filling)')
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+
+    if args.cpu_baseline_only:
+        res = {}
+        for item in args.cpu_baseline_only.split(','):
+            name, _, sec = item.partition('=')
+            res[name] = cpu_baseline(name, float(sec or 3.0))
+        print(json.dumps(res))
+        return
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        launch_ranks(args)                      # this process never touches torch or the GPU
+        return
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU '
+                 '(torch.distributed.run --nproc-per-node %d, or plain `python bench.py --gpus %d`)'
+                 % (args.gpus, world, args.gpus, args.gpus))
+    if args.probe_ranks:                         # launcher / rendezvous check without a GPU (tests)
+        import torch.distributed as dist
+        seen = [None] * world
+        if world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('gloo')
+            dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
+            dist.destroy_process_group()
+        else:
+            seen = [(rank, local_rank, os.getpid())]
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "ranks_seen": len(set(s[0] for s in seen)),
+                              "local_ranks": sorted(s[1] for s in seen), "pids": len(set(s[2] for s in seen)),
+                              "launcher": os.environ.get('BH_BENCH_LAUNCHER', 'external' if world > 1 else None)}))
+        return
+    headline = args.workload == 'joint10' and args.batch is None
+    with_configs = headline and not args.no_configs
+
+    # CPU baseline first, in a child that never initialises the GPU (rank 0, N=1 only)
+    cpu = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        want = ['%s=%g' % (args.workload, 11.0)]
+        if with_configs:
+            want += ['%s=%g' % (c, 2.5) for c in CONFIG_ORDER]
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', ','.join(want)],
+                           capture_output=True, text=True)
+        if r.returncode == 0:
+            cpu = json.loads(r.stdout.strip().splitlines()[-1])
+        else:
+            sys.stderr.write('cpu baseline failed: %s\n' % r.stderr[-2000:])
+
+    import torch
+    import torch.distributed as dist
+    from bayhunter_amd import _lib as bhlib
+
+    # One rank per GPU over RCCL ("nccl").  BH_DIST_BACKEND=gloo is only for rehearsing the N>1 code
+    # path on a box with fewer GPUs than ranks: the ranks then share devices and say so in the line.
+    backend = os.environ.get('BH_DIST_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()              # (does not initialise the GPU)
+    if ndev < 1:
+        sys.exit('bench.py: no GPU visible (there is no CPU fallback)')
+    if ndev < world and backend != 'gloo':
+        sys.exit('bench.py: %d ranks but only %d GPU(s) visible: one rank per GPU is required '
+                 '(BH_DIST_BACKEND=gloo allows sharing, for rehearsal only)' % (world, ndev))
+    dev = local_rank if ndev >= world else local_rank % ndev
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            sys.exit('bench.py: process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
+    ranks = Ranks(world, backend, dev)
+
+    # who is here: every rank's device, gathered over the process group (RCCL with backend nccl)
+    props = torch.cuda.get_device_properties(dev)
+    me = torch.zeros(18, dtype=torch.int64)
+    me[0], me[1] = rank, dev
+    uuid = getattr(props, 'uuid', None)
+    ub = uuid.bytes if uuid is not None and hasattr(uuid, 'bytes') else str(uuid).encode()[:16].ljust(16, b'\0')
+    me[2:18] = torch.tensor(list(ub[:16]), dtype=torch.int64)
+    if world > 1:
+        me = me.to('cuda' if backend == 'nccl' else 'cpu')
+        everyone = [torch.empty_like(me) for _ in range(world)]
+        dist.all_gather(everyone, me)
+        everyone = [e.cpu() for e in everyone]
+    else:
+        everyone = [me]
+    ranks_seen = sorted(int(e[0]) for e in everyone)
+    devices = ['%d:%s' % (int(e[1]), bytes(int(x) for x in e[2:18]).hex()) for e in everyone]
+    devices_seen = len(set(devices))
+    if ranks_seen != list(range(args.gpus)):
+        sys.exit('bench.py: ranks seen %s, expected 0..%d' % (ranks_seen, args.gpus - 1))
+    if backend == 'nccl' and devices_seen != world:
+        sys.exit('bench.py: %d ranks on %d distinct devices' % (world, devices_seen))
+
+    B = args.batch or WORKLOADS[args.workload]['B']
+    head = run_workload(args.workload, B, rank, ranks, args.steps, args.warmup, serial=args.serial)
+    per_rank_ms = [t / args.steps * 1e3 for t in ranks.all_floats(head['dt_local'])]
+    cfg_runs = []
+    if with_configs:
+        for c in CONFIG_ORDER:
+            cfg_runs.append(run_workload(c, WORKLOADS[c]['B'], rank, ranks, 0, 3, serial=args.serial, budget_s=0.6))
 
     if rank == 0:
-        counts, Lmean = N_DLTAR[args.workload]
-        bytes_swd, bytes_rf = algorithmic_bytes(wl, Lmean)
-        flop_swd = sum(counts[r] * (Lmean - 1) * (F_RAYLEIGH if REF_TAGS[r][0] == 2 else F_LOVE)
-                       for r in wl['refs'])
-        flop_rf = (257 * (Lmean - 1) * 500 + Lmean * 300 + 257 * 60 + 5 * 512 * 9) if wl['rf'] else 0.0
-        dom_is_swd = ms_swd >= ms_rf
-        dom_ms = ms_swd if dom_is_swd else ms_rf
-        dom_bytes = (bytes_swd if dom_is_swd else bytes_rf) * B
-        dom_flop = (flop_swd if dom_is_swd else flop_rf) * B
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        from bayhunter_amd import _lib as bhlib
-        dom_kernel = 'swd_kernel' if dom_is_swd else 'rf_kernel'
-        pmc, pmc_note = measured_traffic(dom_kernel, args.workload, B, dom_ms, bhlib.loaded_hash())
-        pmc = pmc or {}
-        traffic = pmc.get('hbm_bytes')
-        tflops = dom_flop / (dom_ms * 1e-3) / 1e12
-        value = world * B * args.steps / dt
+        lib_hash = bhlib.loaded_hash()
+        dom, swd, rf, flop_eval = rooflines(head, lib_hash)
+        value = world * B * args.steps / head['dt']
+        dom = dict(dom, flop_per_eval_reference_path=flop_eval,
+                   note="achieved = reference-path flops / kernel time, timed live with events on the launch "
+                        "stream; traffic and the *_pmc fields come from the committed rocprofv3 --pmc passes and "
+                        "are null unless that profile was taken with this very library and its kernel time "
+                        "matches this run's")
         res = {
             "metric": "forward evals/sec (SWD+RF, 10-layer)" if args.workload == 'joint10'
                       else "forward evals/sec (%s)" % args.workload,
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "warmup": args.warmup, "ms_per_step": head['dt'] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s%s, %s layers, %d periods, %d models/GPU/step"
-                                   % (args.workload, '+'.join(wl['refs']),
-                                      '+prf(201 samples, nsamp 512)' if wl['rf'] else '',
-                                      str(wl['L']), wl['P'], B),
+            "ranks_seen": len(ranks_seen), "devices_seen": devices_seen, "devices": devices,
+            "per_rank_ms_per_step": per_rank_ms, "dist_backend": backend if world > 1 else None,
+            "launcher": os.environ.get('BH_BENCH_LAUNCHER', 'external' if world > 1 else None),
+            "config": {"workload": workload_label(args.workload, B),
                        "models_per_gpu": B, "sharding": "models block-partitioned over ranks, no data-path collective",
-                       "err_models": nerr, "library": bhlib.load().bh_version().decode()},
+                       "err_models": head['nerr'], "library": bhlib.load().bh_version().decode(),
+                       "overlap": not args.serial},
             # The dominant kernel is an fp64 scalar recurrence: FP64 vector issue is the roofline that
             # binds it (SURVEY 8d), so that is the headline fraction; the HBM figure the contract asks
             # for is kept beside it.
-            "roofline": {"kernel": dom_kernel, "bound": "fp64_valu",
-                         "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "algorithmic_flop_per_launch": dom_flop,
-                         "flop_per_eval_reference_path": flop_swd + flop_rf, "n_dltar_per_eval": counts,
-                         "kernel_ms": dom_ms,
-                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": dom_bytes,
-                                 "traffic_bytes_per_launch_pmc": traffic},
-                         "valu_pipes_busy_pmc": pmc.get('valu_busy'),
-                         "lane_utilisation_pmc": pmc.get('lane_utilisation'),
-                         "pmc_source": pmc_note,
-                         "note": "achieved = reference-path flops (N_dltar x (L-1) x 190, FMA = 2) / kernel time, "
-                                 "timed live with events on the launch stream; traffic and the *_pmc fields come "
-                                 "from the committed rocprofv3 --pmc passes and are null unless that profile was "
-                                 "taken with this very library and its kernel time matches this run's"},
-            "kernels_ms": {"swd_kernel": ms_swd, "rf_kernel": ms_rf,
+            "roofline": dom,
+            "roofline_rf": rf,
+            "kernels_ms": {"swd_kernel": head['ms_swd'], "rf_kernel": head['ms_rf'],
                            "note": "serialised; in the timed steps rf_kernel runs on a second stream and back-fills the tail of swd_kernel"},
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu.get(args.workload),
         }
-        if world == 1 and args.workload == 'joint10' and not args.no_chain_pool:
+        if cfg_runs:
+            cfgs = {}
+            for r in cfg_runs:
+                d, s, f, _ = rooflines(r, lib_hash)
+                cfgs[r['name']] = {
+                    "workload": workload_label(r['name'], r['B']),
+                    "value": world * r['B'] * r['steps'] / r['dt'], "unit": "evals/s",
+                    "ms_per_step": r['dt'] / r['steps'] * 1e3, "steps": r['steps'],
+                    "kernel": form_name(r['form']), "kernels_ms": {"swd": r['ms_swd'], "rf": r['ms_rf']},
+                    "roofline_frac": d['frac'],
+                    "roofline": {k: d[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'kernel_ms')},
+                    "hbm_frac": d['hbm']['frac'], "err_models": r['nerr'],
+                    "cpu_baseline": cpu.get(r['name'])}
+            res["configs"] = cfgs
+        if world == 1 and headline and not args.no_chain_pool:
             res["chain_pool"] = chain_pool_sample()
         print(json.dumps(res))
     if world > 1:
+        dist.barrier() if backend != 'nccl' else dist.barrier(device_ids=[dev])
         dist.destroy_process_group()
 
 

@@ -109,6 +109,9 @@ size_t bh_swd_workspace_bytes(int B, int ntargets, const bh_swd_target *targets)
 #define BH_SWD_TEAM256 7 /* 4 waves per search                                                      */
 #define BH_SWD_TEAM512 8 /* 8 waves per search: a handful of deep models                            */
 int bh_swd_set_kernel(int mode);
+/* The kernel form the last bh_swd_batch / bh_swd_batch_ordered of the calling thread launched: 0 = the
+ * lane kernel, otherwise the lanes per search of the team kernel (8 .. 512); -1 before the first call. */
+int bh_swd_last_form(void);
 int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                  const double *vp, const double *vs, const double *rho, int ntargets,
                  const bh_swd_target *targets,
@@ -139,6 +142,10 @@ int bh_swd_order_keys(int B, int Lmax, int model_stride, const int *nlay, const 
 /* qp/qs may be NULL: 500 / 225 like rfmini_modrf.py:119-120.  Output: the first nout samples of
  * the RF trace at out[b*out_stride + out_off + i].  NaN propagates like in the reference. */
 size_t bh_rf_workspace_bytes(int B, int Lmax, const bh_rf_params *par);
+/* Number of frequencies (of nsamp/2 + 1) the kernel computes for these parameters: bins whose Gauss
+ * filter weight exp(-(w/a)^2/4) (greens.cpp:389-392) is below 3e-19 of its value at w = 0 are set to
+ * zero instead (rf_host.h).  0 for invalid parameters.  Host only, no device needed. */
+int bh_rf_active_frequencies(const bh_rf_params *par);
 int bh_rf_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                 const double *vp, const double *vs, const double *rho, const double *qp,
                 const double *qs, /* qp/qs: [B][Lmax] (stride Lmax) or NULL */
@@ -208,6 +215,21 @@ int bh_synrf(int nsamp, double fsamp, double tshift, double p, double a, double 
              int waveno, int nlay, const double *z, const double *vp, const double *vs,
              const double *rh, const double *qp, const double *qs,
              double *fz, double *fr, double *rf);
+
+/* ---- the reference's literal FFI symbols ------------------------------------------------ */
+/* Thin aliases of the two drop-ins above under the names the reference's generated glue binds, so that
+ * the f2py wrapper of surfdisp96.f and rfmini.pyx link against this library unchanged:
+ *   surfdisp96_   the Fortran symbol of `subroutine surfdisp96` (surfdisp96.f:55-56): thirteen
+ *                 arguments, all by reference, no return value; *err as the reference, or 100 + BH_ERR_*
+ *                 when the library itself failed (message on stderr and in bh_last_error())
+ *   synrf_cwrap   wrap.cpp:57-63, exact signature; returns 1 like the reference (0 and NaN traces when
+ *                 the library itself failed) */
+void surfdisp96_(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                 const int *nlayer, const int *iflsph, const int *iwave, const int *mode, const int *igr,
+                 const int *kmax, const double *t, double *cg, int *err);
+int synrf_cwrap(int nsamp, double fsamp, double tshift, double p, double a, double nsv, double sigma,
+                int waveno, int nlay, double *z, double *vp, double *vs, double *rh, double *qp, double *qs,
+                double *fz, double *fr, double *rf);
 
 /* ---- self-test --------------------------------------------------------------------------- */
 /* The surface-wave kernels divide with a shared-reciprocal form of the compiler's own IEEE sequence

@@ -19,6 +19,14 @@ int main(int argc, char **argv)
         rc = bh_surfdisp96(m, m, m, m, 101, 0, 2, 1, 0, 1, t, cg, &err);
         if (rc != BH_ERR_ARG) { printf("expected BH_ERR_ARG, got %d\n", rc); return 3; }
         printf("arg check ok: %s\n", bh_last_error());
+        {   /* the same through the reference's own Fortran symbol (surfdisp96.f:55-56: all by reference):
+             * a failure of the library shows as err = 100 + BH_ERR_* (and a line on stderr) */
+            int nl = 101, zero = 0, one = 1, two = 2;
+            err = -1;
+            surfdisp96_(m, m, m, m, &nl, &zero, &two, &one, &zero, &one, t, cg, &err);
+            if (err != 100 + BH_ERR_ARG) { printf("surfdisp96_: expected err %d, got %d\n", 100 + BH_ERR_ARG, err); return 3; }
+            printf("literal names ok\n");
+        }
     }
     {   /* the chain-pool loop from C (host code only): propose -> [likelihoods] -> accept.  The
          * "likelihood" here is a made-up function of the proposal; real callers run bh_swd_batch /
@@ -79,6 +87,19 @@ int main(int argc, char **argv)
         if (rc != BH_OK) { printf("bh_synrf failed: %s\n", bh_last_error()); return 5; }
         for (k = 0; k < 201; k++) printf("rf %.17g\n", rf[k]);
         (void)hd;
+        {   /* the literal FFI names the reference's f2py / Cython glue binds */
+            int nl = 4, flsph = 0, iwave = 2, mode = 1, igr = 0, kmax = 21;
+            double cg2[60], fz[512], fr[512], rf2[512];
+            double kk = vpd[0] / vsd[0], sigma = (2 - kk * kk) / (2 - 2 * kk * kk);
+            err = -1;
+            surfdisp96_(h, vp, vs, rho, &nl, &flsph, &iwave, &mode, &igr, &kmax, per, cg2, &err);
+            printf("err2 %d\n", err);
+            for (k = 0; k < 21; k++) printf("cg2 %.17g\n", cg2[k]);
+            rc = synrf_cwrap(512, 5.0, 5.0, 6.4, 1.0, vsd[0], sigma, 0, 4, z, vpd, vsd, rhod, qp, qs, fz, fr, rf2);
+            printf("synrf_cwrap returned %d\n", rc);
+            for (k = 0; k < 201; k++) printf("rf2 %.17g\n", rf2[k]);
+            printf("fz0 %.17g fr0 %.17g\n", fz[25], fr[25]);
+        }
     }
     return 0;
 }

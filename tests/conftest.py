@@ -87,10 +87,12 @@ def _wrap_hostsim(hs):
 
         @staticmethod
         def rf(h, vp, vs, rho, p=6.4, gauss=1.0, nsamp=512, fsamp=5.0, tshift=5.0, nsv=None,
-               waveno=0, nout=201):
+               waveno=0, nout=201, qp=None, qs=None):
             a = [np.ascontiguousarray(x, dtype=np.float64) for x in (h, vp, vs, rho)]
+            q = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (qp, qs)]
             out = np.zeros(nout)
-            hs.hs_rf(len(a[0]), *[x.ctypes.data_as(dp) for x in a], None, None, p, gauss, nsamp,
+            hs.hs_rf(len(a[0]), *[x.ctypes.data_as(dp) for x in a],
+                     *[None if x is None else x.ctypes.data_as(dp) for x in q], p, gauss, nsamp,
                      fsamp, tshift, -1.0 if nsv is None else nsv, waveno, nout,
                      out.ctypes.data_as(dp))
             return out

@@ -137,6 +137,7 @@ def test_clients_raise_when_a_launch_fails():
     errs = [m for m in msgs if m[0] == 'err']
     assert len(errs) == 2 and all('simulated HIP error' in m[1] for m in errs)
     assert not alive and 'simulated HIP error' in br.error()
+    assert br.exitcode == 1                # a failed GPU process must not look like a clean exit
 
 
 def test_clients_raise_when_the_server_is_killed():
@@ -148,5 +149,8 @@ def test_clients_raise_when_the_server_is_killed():
 
 def test_start_reports_a_back_end_that_cannot_be_created():
     from bayhunter_amd.broker import BrokerError, ForwardBroker
+    br = ForwardBroker(swd=[('rdispph', np.array([1., 2., 3.]))], backend_factory=_broken_factory)
     with pytest.raises(BrokerError, match='no usable device'):
-        ForwardBroker(swd=[('rdispph', np.array([1., 2., 3.]))], backend_factory=_broken_factory).start()
+        br.start()
+    br._proc.join(timeout=30)
+    assert br._proc.exitcode == 1

@@ -25,7 +25,8 @@ def test_header_is_c99_and_links(lib):
     _build(lib)
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert 'bayhunter_amd' in r.stdout and 'arg check ok' in r.stdout
+    assert 'bayhunter_amd' in r.stdout and 'arg check ok' in r.stdout and 'literal names ok' in r.stdout
+    assert 'surfdisp96_ failed' in r.stderr          # the library says why on stderr
     assert 'chains ok: 61 rounds, iteration 30' in r.stdout          # initial models + 60 iterations
 
 
@@ -39,3 +40,8 @@ def test_c_consumer_runs_tutorial_model(lib, golden):
     assert 'err 0' in r.stdout
     assert np.array_equal(cg, golden['tutorial_full']['rdispph'])
     assert np.abs(rf - golden['tutorial_full']['prf']).max() <= 1e-10
+    # the same model through the reference's literal FFI symbols (surfdisp96_, synrf_cwrap)
+    cg2 = np.array([float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith('cg2 ')])
+    rf2 = np.array([float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith('rf2 ')])
+    assert 'err2 0' in r.stdout and 'synrf_cwrap returned 1' in r.stdout
+    assert np.array_equal(cg2, cg) and np.array_equal(rf2, rf)

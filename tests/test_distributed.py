@@ -196,3 +196,49 @@ def test_gloo_world4_gather_to_root_ragged_and_thinned():
         w = one.weighted(i)[2]
         thin = int(np.ceil(w[1].size / 17.0))
         assert np.array_equal(want[:, :one.models.shape[2]], w[0][::thin].astype(np.float32), equal_nan=True)
+
+
+# ---- a proper sub-group: its ranks are not 0..n-1 of the world -----------------------------------
+def _subgroup_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from bayhunter_amd.distributed import gather_ragged_to_root, gather_rows_to_root
+    members = [1, 3]                                       # world ranks 1 and 3 are ranks 0 and 1 of the group
+    grp = dist.new_group(members)                          # (every process must take part in new_group)
+    res = None
+    if rank in members:
+        gr = members.index(rank)
+        n = 5
+        lo, hi = shard_range(n, gr, 2)
+        rows = torch.arange(n * 2, dtype=torch.float32).reshape(n, 2)[lo:hi]
+        full = gather_rows_to_root(rows, n, dst=1, group=grp)            # root = group rank 1 = world rank 3
+        rag = gather_ragged_to_root(torch.full((gr + 2, 3), float(rank)), dst=0, group=grp)
+        t = max_over_ranks(float(rank), group=grp)
+        res = (None if full is None else full.numpy(), None if rag is None else [r.numpy() for r in rag], t)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_subgroup_gathers_address_the_right_peers():
+    """Gathers inside a sub-group {1, 3} of a 4-rank world: group ranks must be translated to world
+    ranks for send / irecv / gather, otherwise the blocks go to (or hang on) the wrong peers."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(4))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] is None and got[2] is None
+    full1, rag1, t1 = got[1]
+    full3, rag3, t3 = got[3]
+    assert full1 is None and np.array_equal(full3, np.arange(10, dtype=np.float32).reshape(5, 2))
+    assert rag3 is None and [a.shape for a in rag1] == [(2, 3), (3, 3)]
+    assert (rag1[0] == 1).all() and (rag1[1] == 3).all()
+    assert t1 == 3.0 and t3 == 3.0

@@ -508,6 +508,27 @@ def test_synrf_dropin_returns_all_three_traces(lib, oracle):
             assert np.array_equal(rf, rf2)
 
 
+def test_rf_frequency_cutoff_on_resonant_low_q_models(lib, oracle):
+    """bh_synrf against the oracle on models with extreme spectral ratios (thin slow surface layer, small
+    Q, Gauss factor <= 1.2: tests/rf_extreme.py).  The kernel drops the frequencies whose filter weight is
+    below 3e-19, the reference computes all 257: the result must still be within TOL_RF."""
+    from bayhunter_amd import _lib
+    from rf_extreme import resonant_models
+    worst, finite = 0.0, 0
+    for m in resonant_models(120):
+        want = oracle.synrf(m['z'], m['vp'], m['vs'], m['rho'], m['qp'], m['qs'], m['p'], m['gauss'], 512, 5.0, 5.0,
+                            m['vs'][0], m['sigma'], m['waveno'])[2]
+        a = [np.ascontiguousarray(m[k]) for k in ('z', 'vp', 'vs', 'rho', 'qp', 'qs')]
+        rf = np.zeros(512)
+        _lib.check(lib.bh_synrf(512, 5.0, 5.0, m['p'], m['gauss'], m['vs'][0], m['sigma'], m['waveno'], a[0].size,
+                                *[x.ctypes.data for x in a], None, None, rf.ctypes.data))
+        assert np.array_equal(np.isfinite(want), np.isfinite(rf))
+        if np.isfinite(want).all():
+            finite += 1
+            worst = max(worst, np.abs(rf - want).max() / max(1.0, np.abs(want).max()))
+    assert finite >= 90 and worst <= TOL_RF, (finite, worst)
+
+
 def test_ragged_batch_is_reordered_transparently(lib, oracle):
     """Above 8192 models the searches are processed deepest first and by S travel time within a
     depth (a permutation handed to bh_swd_batch_ordered); results land in the caller's rows,
@@ -627,6 +648,13 @@ def test_model_deeper_than_the_launch_is_flagged_not_truncated(lib, oracle):
         out, err = out.cpu().numpy(), err.cpu().numpy()
         assert np.all(err[bad] == 2) and np.all(np.isnan(out[bad])), mode
         assert np.array_equal(err[good, 0], werr[good]) and np.array_equal(out[good, :21][werr[good] == 0], want[good][werr[good] == 0]), mode
+    # a receiver-function-only engine has no dispersion kernel to raise the flag: same contract
+    rf_only = ForwardEngine(rf=[RfSpec('prf', np.linspace(-5, 35, 201))])
+    out, err = rf_only.run(hinted)
+    torch.cuda.synchronize()
+    out, err = out.cpu().numpy(), err.cpu().numpy()
+    assert err.shape == (300, 1) and np.all(err[bad, 0] == 2) and np.all(err[good] == 0)
+    assert np.all(np.isnan(out[bad])) and not np.isnan(out[good]).any()
 
 
 @pytest.mark.parametrize('kernel', ['lane', 'team', 'team256', 'team16'])

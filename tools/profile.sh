@@ -7,8 +7,10 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline ${@:2}"
-echo "bench.py --steps 5 --warmup 2 --no-cpu-baseline ${@:2}" > $OUT/config.txt
+# --serial: rf_kernel runs behind swd_kernel on one stream, so rocprof's per-kernel durations are kernel
+# times (with the product's side stream rf_kernel overlaps the tail of swd_kernel: 19-67 ms per dispatch)
+BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-chain-pool --no-configs --serial ${@:2}"
+echo "bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-chain-pool --no-configs --serial ${@:2}" > $OUT/config.txt
 (cd $R && python3 -c "from bayhunter_amd import _lib; print(_lib.loaded_hash())") > $OUT/src_hash.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
