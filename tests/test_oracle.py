@@ -191,3 +191,65 @@ np.savez(sys.argv[1], **r)
         assert rel.max() > 0.05 * tol, (name, rel.max())          # ... and of its order: not bit-identical
         assert (rel == 0).mean() >= 0.99
     assert np.array_equal(a['lph'], b['lph'])                     # Love: well conditioned, identical
+
+
+# ---- the worst LVZ deviations of the random campaigns, against the reference's own behaviour --------
+def _lvz_cases():
+    z = np.load(os.path.join(GOLDEN, 'lvz_worst_cases.npz'))
+    return z, ['c%d_' % i for i in range(int(z['ncases']))]
+
+
+def test_lvz_worst_cases_fixture_is_the_oracles(oracle):
+    """tests/golden/lvz_worst_cases.npz (made with the reference binary, tests/scenarios/lvz_worst_cases.py):
+    the C restatement returns the reference's values and phase velocities bit for bit."""
+    z, cases = _lvz_cases()
+    for p in cases:
+        a = [z[p + k] for k in ('H', 'VP', 'VS', 'RHO', 'nl', 'per')]
+        val, err, _ = oracle.swd_batch(*a, int(z[p + 'iwave']), int(z[p + 'igr']), int(z[p + 'mode']), int(z[p + 'fl']))
+        ph, _, _ = oracle.swd_batch(*a, int(z[p + 'iwave']), 0, int(z[p + 'mode']), int(z[p + 'fl']))
+        assert np.array_equal(val, z[p + 'ref_fma']) and np.array_equal(err, z[p + 'ref_err']), p
+        assert np.array_equal(ph, z[p + 'ref_phase']), p
+
+
+def test_lvz_worst_deviations_are_the_references_own_spread(oracle, hostsim_devmath):
+    """The campaign's largest deviations (1.51e-2 and 4.5e-3 in group velocity, 1.99e-6 in phase velocity,
+    profiles/r02_kernel_fuzz.txt) are what the REFERENCE does at those models when its libm is accurate to
+    1 ulp: (a) in the committed runs of the reference under <= 1 ulp noise the worst value of every case
+    takes the device's value bit for bit in some runs; (b) the same experiment repeated live with the C
+    restatement under the shim reproduces those runs; (c) every value of the device replay is within the
+    bound that includes the conditioning term U/c (tests/tolerances.py)."""
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    from tolerances import TOL_PHASE_2BRACKETS, group_bound
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'scenarios'))
+    import lvz_worst_cases as lw
+    z, cases = _lvz_cases()
+    seen_big = 0
+    for i, p in enumerate(cases):
+        ref, noise, c = z[p + 'ref_fma'], z[p + 'ref_noise'], z[p + 'ref_phase']
+        dev = lw.device_replay(z, i)
+        assert np.array_equal(dev, z[p + 'device_replay']), p           # the replay is deterministic
+        nz = (ref != 0) & (z[p + 'ref_err'] == 0)[:, None]
+        rel = np.zeros_like(ref)
+        rel[nz] = np.abs(dev[nz] - ref[nz]) / np.abs(ref[nz])
+        bound = group_bound(ref, c) if int(z[p + 'igr']) else np.full_like(ref, TOL_PHASE_2BRACKETS)
+        assert np.all(rel <= bound), (p, rel.max())
+        b, k = np.unravel_index(np.argmax(rel), rel.shape)
+        values = set(noise[:, b, k].tolist())
+        assert dev[b, k] in values and ref[b, k] in values, (p, dev[b, k], sorted(values))
+        spread = (max(values) - min(values)) / abs(ref[b, k])
+        assert spread >= 0.99 * rel[b, k], (p, spread, rel[b, k])       # the reference moves as far itself
+        seen_big += int(rel[b, k] > 1e-3)
+    assert seen_big >= 2                                                  # the 1.5e-2 and 4.5e-3 cases are in
+    # (b) live: the restatement under the shim, four of the noise seeds
+    try:
+        lw.build_noise_lib()
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip('cannot build the libm shim here')
+    seeds = [0, 5, 11, 17]
+    runs = lw.solve_children(lw.FIXTURE, 'port', ['noise%d' % s for s in seeds])
+    for p in cases:
+        for s in seeds:
+            assert np.array_equal(runs['noise%d' % s][p + 'val'], z[p + 'ref_noise'][s]), (p, s)

@@ -34,7 +34,35 @@ low-velocity-zone models by up to 1.02e-6 relative in phase velocity and 4.3e-4 
 in group velocity, 99.69-99.99 % of the values identical; Love and monotone models: identical.
 The device against the reference (profiles/parity_r01.txt): 1.01e-6, 5.7e-4 (2.0e-4 relative),
 99.2-99.9 % identical.
+
+Round 3 closed the question for the worst values of those campaigns (tests/scenarios/lvz_worst_cases.py,
+tests/golden/lvz_worst_cases.npz, profiles/r03_lvz_worst_cases.txt): the models behind the 1.51e-2, 4.5e-3
+(group) and 1.99e-6, 1.88e-6 (phase) lines were re-derived from the campaign seeds and handed to the
+reference's own binary under a libm whose sin/cos/exp are moved by <= 1 ulp (an LD_PRELOAD shim; 24 noise
+seeds).  At exactly those models and periods the REFERENCE then returns the device's value, bit for bit,
+in some of the runs and its usual value in the others: 610.66 vs 619.89 km/s (U/c = 257), -234.96 vs
+-236.02 (U/c = -68, second mode), 2.51754999 vs 2.51754498.  The deviation class is therefore asserted,
+not just printed, against the bound that includes the conditioning term:
+
+  phase  |dc|/c <= 2e-6 (two stopping brackets) + fp32 rounding of the stored value
+  group  |dU|/|U| <= 4e-4 * |U/c|: with U = (2h/t) / ((1+h)/(t c0) - (1-h)/(t c1)), a relative change e0, e1
+         of c0, c1 changes U by (|e0| + |e1|) |U| / (2 h c); e <= 2e-6 each, h = 0.005 (surfdisp96.f:232-306)
 """
+import numpy as np
+
+TOL_PHASE_2BRACKETS = 2.2e-6    # two runs, each anywhere in its own 1e-6 bracket, + fp32 output rounding
+
+
+def group_bound(U, c):
+    """Largest relative difference of two group velocities computed from phase velocities that each sit
+    anywhere inside the search's own stopping bracket (surfdisp96.f:614), as a function of U/c; never
+    below the single-bracket figure asserted on ordinary models."""
+    U, c = np.asarray(U, dtype=np.float64), np.asarray(c, dtype=np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ratio = np.where(c != 0, np.abs(U / c), np.inf)
+    return np.maximum(TOL_GROUP_REL, 4.2e-4 * ratio)
+
+
 TOL_PHASE_REL = 1.2e-6          # derived: 1e-6 (stopping bracket) + fp32 rounding of the output
 TOL_GROUP_REL = 2.5e-4          # derived: 2e-4 * U/c + fp32 cancellation
 TOL_PHASE = TOL_PHASE_REL * 5.0  # absolute forms for c, U <= 5 km/s (vs prior 2..5 km/s)
