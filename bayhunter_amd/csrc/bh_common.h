@@ -169,19 +169,35 @@ BH_DEV cd crecip(cd z)
     return mk(z.re * r, -(z.im * r));
 }
 
-// principal square root for generic complex arguments of the recursion (im != 0)
+// sqrt(x) and 1/(2 sqrt(x)) from one v_rsq_f64 seed (the coupled Newton iteration of fsqrt carries both)
+#if defined(BH_HOSTSIM)
+BH_DEV void fsqrt_hinv(double x, double *g, double *h) { *g = sqrt(x); *h = 0.5 / *g; }
+#else
+BH_DEV void fsqrt_hinv(double x, double *gout, double *hout)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    r = __builtin_fma(-h, g, 0.5);                // one more step on h: ~1 ulp like frcp
+    h = __builtin_fma(h, r, h);
+    *gout = g;
+    *hout = h;
+}
+#endif
+
+// principal square root for generic complex arguments of the recursion (im != 0): with m = the larger of
+// the two roots sqrt((|z| +- re)/2), the other one is im / (2 m)
 BH_DEV cd csqrt_fast(cd z)
 {
     double re = z.re, im = z.im;
-    double d = fsqrt(re * re + im * im), r, s;
-    if (re > 0) {
-        r = fsqrt(0.5 * (d + re));
-        s = 0.5 * (im * frcp(r));
-    } else {
-        s = fsqrt(0.5 * (d - re));
-        r = fabs(0.5 * (im * frcp(s)));
-    }
-    return mk(r, copysign(s, im));
+    double d = fsqrt(re * re + im * im), m, hinv;
+    fsqrt_hinv(0.5 * (d + fabs(re)), &m, &hinv);
+    const double o = im * hinv;                   // im / (2 m)
+    return (re > 0) ? mk(m, o) : mk(fabs(o), copysign(m, im));
 }
 
 // principal square root, glibc csqrt's formulation for finite non-zero arguments

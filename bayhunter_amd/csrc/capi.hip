@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 #include "../../include/bayhunter_amd.h"
 #include "kernels.h"
@@ -72,6 +73,31 @@ int get_twiddles(int nsamp, const double **out)
         BH_HIP(hipMalloc((void **)&d, tw.size() * sizeof(double)));
         BH_HIP(hipMemcpy(d, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
         it = g_tw.emplace(key, d).first;
+    }
+    *out = it->second;
+    return BH_OK;
+}
+
+// Per-frequency constants of the receiver-function kernel (rf_host.h, rf_fill_freq_table): one table per
+// (device, nsamp, fsamp, gauss, tshift), built on the host with the reference's expressions.  A run uses a
+// handful of parameter sets; tables are small (24 bytes per frequency) and live until the process ends
+// (a launch in flight may still read them).
+std::map<std::tuple<int, int, double, double, double>, double *> g_ftab;
+
+int get_freq_table(const bh::RfLaunch &P, double fsamp, const double **out)
+{
+    int dev = 0;
+    BH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto key = std::make_tuple(dev, P.nsamp, fsamp, P.gauss, P.tshift);
+    auto it = g_ftab.find(key);
+    if (it == g_ftab.end()) {
+        std::vector<double> tab((size_t)bh::RF_FTAB * P.nfreq);
+        bh::rf_fill_freq_table(P, tab.data());
+        double *d = nullptr;
+        BH_HIP(hipMalloc((void **)&d, tab.size() * sizeof(double)));
+        BH_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = g_ftab.emplace(key, d).first;
     }
     *out = it->second;
     return BH_OK;
@@ -392,6 +418,8 @@ static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, 
     if (bh::rf_lds_bytes(Lmax, n, 1, out_fz && out_fr) > 160 * 1024) return fail_arg("model does not fit LDS");
     A.out_fz = out_fz; A.out_fr = out_fr;
     rc = get_twiddles(n, &A.tw);
+    if (rc) return rc;
+    rc = get_freq_table(A.P, par->fsamp, &A.ftab);
     if (rc) return rc;
     A.B = B; A.mstride = model_stride; A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.qp = qp; A.qs = qs;
     A.out = out;

@@ -36,6 +36,7 @@ struct RfArgs {
     const int *nlay;
     const double *h, *vp, *vs, *rho, *qp, *qs;
     const double *tw;  // FFT twiddles, rf_host.h
+    const double *ftab; // per-frequency constants [nfreq][3], rf_host.h (rf_fill_freq_table)
     double *out;
     double *out_fz, *out_fr;  // optional [B][nsamp] vertical / radial traces (synrf_cwrap's fz, fr)
     RfLaunch P;

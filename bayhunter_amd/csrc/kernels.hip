@@ -844,14 +844,15 @@ __global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         int nl = A.nlay[b0 + m];
         nl = nl < 1 ? 1 : (nl > L ? L : nl);
         double *Sm = S + (long)m * pm;
+        const RfFreq F = rf_freq_load(A.ftab, j);
         if (ZR) {
             cd zr_r, zr_z;
-            cd crf = rf_phase3_task(Sm, lo, P, nl, j, &zr_r, &zr_z);
+            cd crf = rf_phase3_task(Sm, lo, P, nl, j, F, &zr_r, &zr_z);
             rf_xst(Sm, j, crf);
             st_cd(Sm + lo.per_model + 2 * j, zr_r);
             st_cd(Sm + lo.per_model + 2 * P.nfreq + 2 * j, zr_z);
         } else {
-            cd crf = rf_phase3_task(Sm, lo, P, nl, j);
+            cd crf = rf_phase3_task(Sm, lo, P, nl, j, F);
             rf_xst(Sm, j, crf);
         }
     }

@@ -292,18 +292,36 @@ BH_DEV void rf_phase2_interface(double *S, const RfLayout &lo, const RfLaunch &P
 }
 
 // ---- P3: one frequency of one model (greens.cpp:528-585 + compute_rf :377-395) ----------------------
+// What a frequency needs that does not depend on the model: ln(w/wref) of the anelastic velocities
+// (greens.cpp:530,539-540) and the Gauss filter x time shift factor of compute_rf (:389-392).  Both come
+// from a table the host fills with the reference's own expressions (rf_host.h, rf_fill_freq_table) --
+// glibc's log and std::exp(Complex), bit for bit what rfmini uses -- instead of a device log, exp and
+// sincos per (model, frequency).  Three doubles per frequency: lgw, re(cq), im(cq).
+struct RfFreq {
+    double lgw;
+    cd cq;
+};
+enum { RF_FTAB = 3 };
+BH_DEV RfFreq rf_freq_load(const double *BH_RESTRICT ftab, int j)
+{
+    RfFreq F;
+    F.lgw = ftab[RF_FTAB * j];
+    F.cq = mk(ftab[RF_FTAB * j + 1], ftab[RF_FTAB * j + 2]);
+    return F;
+}
+
 #if !defined(BH_HOSTSIM)
 #pragma clang fp contract(fast)
 #endif
 template <class M>
 BH_DEV cd rf_phase3_body(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j,
-                         cd *zr_r, cd *zr_z)
+                         const RfFreq &F, cd *zr_r, cd *zr_z)
 {
     const double *par = S + lo.off_par;
     const double *coef = S + lo.off_coef;
     const double *sc = S + lo.off_sc;
     const double w = P.dw * j;
-    const double lgw = j ? log(w / P.wref) : 0;
+    const double lgw = F.lgw;
     cm2 nb = cm2_zero(), q = cm2_zero(), g = cm2_zero();
     // complex velocity v (1 + ln(w/wref)/(pi Q) + i/(2 Q)), Mueller (1985) eq. 132: 1/v_c^2 =
     // (1/v^2) * 1/f^2 with f the bracket; with one Q for all layers f is a per-frequency constant
@@ -355,9 +373,18 @@ BH_DEV cd rf_phase3_body(const double *S, const RfLayout &lo, const RfLaunch &P,
     cm2 t = ld_cm2(sc + RF_SC_H2) * g;                            // t = 2*h*g[nlay-1]
     cd cr, cz;
     if (P.waveno == 0) { cr = t.c11; cz = t.c21; } else { cr = t.c12; cz = t.c22; }
-    cd qq = cexp_(mk(0., w * sc[RF_SC_T0]));
-    cr = cr * qq;
-    cz = cz * qq;
+    // exp(i w t0), the direct-wave delay (greens.cpp:583-585): a unit factor common to cr and cz.  The
+    // vertical / radial spectra need it; the receiver function is their ratio, in which it cancels -- all
+    // that must survive is the reference's NaN when t0 is (post-critical incidence: the root of a negative
+    // number in the delay sum, greens.cpp:510-526).
+    if (zr_r) {
+        cd qq = cexp_(mk(0., w * sc[RF_SC_T0]));
+        cr = cr * qq;
+        cz = cz * qq;
+    } else {
+        const double t0nan = sc[RF_SC_T0] * 0.0;                  // 0, or NaN for a NaN / infinite delay
+        cr = cr + mk(t0nan, t0nan);
+    }
     if (sc[RF_SC_DECOMP] != 0.0) {                                // decomp, greens.cpp:335-340
         cd cx = cz * sc[RF_SC_M11] + cr * sc[RF_SC_M12];
         cd cy = cz * sc[RF_SC_M21] + cr * sc[RF_SC_M22];
@@ -368,23 +395,21 @@ BH_DEV cd rf_phase3_body(const double *S, const RfLayout &lo, const RfLaunch &P,
     if (P.waveno == 1) { cd tmp = cz; cz = cr; cr = tmp; }        // greens.cpp:369-373
     double denom = cz.re * cz.re + cz.im * cz.im;                 // real(cz*conj(cz)); no water level
     cd crf = (cr * conj(cz)) / denom;
-    double wa = w / P.gauss;
-    wa = (wa > 50.0) ? 50.0 : wa;
-    cd cq = cexp_(mk(-0.25 * (wa * wa), -w * P.tshift)) * P.qgauss;
+    const cd cq = F.cq;                                           // q exp(-(w/a)^2/4 - i w tshift), host table
     if (zr_r) { *zr_r = arr_r * cq; *zr_z = arr_z * cq; }       // greens.cpp:393-394 (for iftr2)
     return crf * cq;
 }
 
 BH_DEV cd rf_phase3_task(const double *S, const RfLayout &lo, const RfLaunch &P, int nlay, int j,
-                         cd *zr_r = nullptr, cd *zr_z = nullptr)
+                         const RfFreq &F, cd *zr_r = nullptr, cd *zr_z = nullptr)
 {
     // all interface matrices of this model real (no post-critical wave anywhere): half the
     // multiplications in the products with rd, td, ru, tu
     const double *flag = S + lo.off_par + 8 * lo.L;
     bool real = true;
     for (int i = 0; i < nlay; i++) real = real && flag[i] != 0.0;
-    return real ? rf_phase3_body<rm2>(S, lo, P, nlay, j, zr_r, zr_z)
-                : rf_phase3_body<cm2>(S, lo, P, nlay, j, zr_r, zr_z);
+    return real ? rf_phase3_body<rm2>(S, lo, P, nlay, j, F, zr_r, zr_z)
+                : rf_phase3_body<cm2>(S, lo, P, nlay, j, F, zr_r, zr_z);
 }
 
 #if !defined(BH_HOSTSIM)

