@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
-SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip", "chains.cpp"]
+SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip", "evalplan.hip", "chains.cpp"]
 HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "swd_team.h", "rf_core.h", "rf_host.h", "kernels.h"]
 # -disable-machine-licm (device code only): the kernels are register-bound, and constants hoisted out
 # of the persistent loops (polynomial coefficients, masks) end up in VGPR pairs or spilled SGPRs and are
@@ -42,6 +42,12 @@ class LikeTarget(C.Structure):
     """struct bh_like_target"""
     _fields_ = [("n", C.c_int), ("off", C.c_int), ("cov", C.c_int), ("aux_off", C.c_int),
                 ("logdet_extra", C.c_double)]
+
+
+class EvalInterp(C.Structure):
+    """struct bh_eval_interp"""
+    _fields_ = [("target", C.c_int), ("dst_off", C.c_int), ("n_dst", C.c_int), ("_pad", C.c_int),
+                ("obsx", C.c_void_p)]
 
 
 class ModelPriors(C.Structure):
@@ -149,6 +155,13 @@ _SIGS = {
                                     C.POINTER(C.c_double)]),
     "bh_chains_set_rng": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_double]),
     "bh_chains_draw": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp]),
+    "bh_eval_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SwdTarget), _vp, C.c_int, C.c_int,
+                                 C.POINTER(RfParams), C.c_int, C.POINTER(LikeTarget), C.c_int, _vp, _vp, C.c_size_t,
+                                 C.c_int, C.POINTER(EvalInterp), C.c_int, C.POINTER(_vp)]),
+    "bh_eval_destroy": (None, [_vp]),
+    "bh_eval_buffers": (C.c_int, [_vp] + [C.POINTER(_vp)] * 5),
+    "bh_eval_submit": (C.c_int, [_vp, C.c_int]),
+    "bh_eval_wait": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "bh_version": (C.c_char_p, []),
     "bh_last_error": (C.c_char_p, []),
     "bh_device_count": (C.c_int, [C.POINTER(C.c_int)]),

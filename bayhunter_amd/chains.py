@@ -60,70 +60,40 @@ class _CallEvaluator(object):
 
 
 class GpuEvaluator(object):
-    """Proposals -> (logL, misfits) on the device through JointTarget.evaluate_batch.  Proposals are
-    written by the library straight into pinned host buffers; upload, kernels and the download of
-    8*(ntargets+2) bytes per model are queued on the group's own stream and `collect` waits for its
-    event, so the batches of different groups overlap on the device as far as it has room."""
+    """Proposals -> (logL, misfits) on the device, one evaluation plan of the library per chain group
+    (evalplan.EvalPlan / bh_eval_*): the library writes the proposals straight into the plan's pinned
+    staging block, `submit` is ONE call -- upload, processing order, dispersion / receiver-function /
+    likelihood kernels and the download of 8*(ntargets+2) bytes per model are queued on the plan's own
+    streams -- and `collect` waits for its event, so the batches of different groups overlap on the device
+    as far as it has room.  (Until round 3 this was a sequence of torch calls per batch: as much host time
+    as the device needed for the arithmetic at 4 096 chains.)"""
 
     def __init__(self, joint, device=None):
-        import torch
-        self.torch = torch
         self.joint = joint
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        self._pin = {}
+        if device is not None:
+            dev = device if isinstance(device, int) else getattr(device, 'index', None)
+            if dev is None:
+                dev = int(str(device).split(':')[1]) if ':' in str(device) else 0
+            _lib.check(_lib.load().bh_set_device(int(dev)))
+        self._plans = {}
 
     def buffers(self, rows, Lmax, ntargets):
-        """One pinned block per group, [packed | noise | nlay | chain], so that a batch goes up in ONE
-        copy (every host->device call costs ~60 us of host time, which is what a small pool waits
-        for); results come down in one block [logL | misfits] as well."""
-        torch = self.torch
-        nd = rows * 4 * Lmax + rows * 2 * ntargets          # doubles in front
-        block = torch.zeros(nd + rows, dtype=torch.float64).pin_memory()      # + 2 int32 per row
-        host = block.numpy()
-        packed = host[:rows * 4 * Lmax].reshape(rows, 4, Lmax)
-        noise = host[rows * 4 * Lmax:nd].reshape(rows, 2 * ntargets)
-        ints = host[nd:].view(np.int32)
-        nlay, chain = ints[:rows], ints[rows:2 * rows]
-        outs = torch.zeros(rows * (ntargets + 2), dtype=torch.float64).pin_memory()
-        self._pin[packed.ctypes.data] = dict(block=block, outs=outs, rows=rows, Lmax=Lmax, T=ntargets, nd=nd,
-                                             stream=torch.cuda.Stream(device=self.device))
-        return packed, nlay, noise, chain
+        plan = self.joint.eval_plan(rows, Lmax)
+        assert plan.T == ntargets
+        self._plans[plan.packed.ctypes.data] = plan
+        return plan.packed, plan.nlay, plan.noise, plan.chain
 
     def submit(self, group, packed, nlay, noise):
-        torch = self.torch
-        B = packed.shape[0]
-        if B == 0:
+        if packed.shape[0] == 0:
             return None
-        st = self._pin[packed.ctypes.data]
-        rows, Lmax, T, nd = st['rows'], st['Lmax'], st['T'], st['nd']
-        with torch.cuda.stream(st['stream']):
-            # small pools: the whole block in one copy; large ones: only the used part of each section
-            if rows <= 16384:
-                d = st['block'].to(self.device, non_blocking=True)
-                dp = d[:rows * 4 * Lmax].view(rows, 4, Lmax)[:B]
-                dz = d[rows * 4 * Lmax:nd].view(rows, 2 * T)[:B]
-                dn = d[nd:].view(torch.int32)[:B]
-            else:
-                blk = st['block']
-                dp = blk[:B * 4 * Lmax].to(self.device, non_blocking=True).view(B, 4, Lmax)
-                dz = blk[rows * 4 * Lmax:rows * 4 * Lmax + B * 2 * T].to(self.device, non_blocking=True).view(B, 2 * T)
-                dn = blk[nd:].view(torch.int32)[:B].to(self.device, non_blocking=True)
-            # proposals of one iteration have ragged depths: the engine groups large batches by depth
-            bt = self.joint._batch or self.joint._build_batch()
-            logL, misfits = self.joint.evaluate_batch(bt['eng'].reorder(dp, dn, ragged=True, depth=int(nlay.max())),
-                                                      noise=dz)
-            st['outs'][:B * (T + 2)].copy_(torch.cat((logL, misfits.reshape(-1))), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(st['stream'])
-        return ev, st['outs'], B, T
+        plan = self._plans[packed.ctypes.data]
+        plan.submit(packed.shape[0])
+        return plan
 
     def collect(self, ticket):
         if ticket is None:
             return np.zeros(0), np.zeros((0, self.joint.ntargets + 1))
-        ev, outs, B, T = ticket
-        ev.synchronize()
-        host = outs.numpy()
-        return host[:B], host[B:B * (T + 2)].reshape(B, T + 1)
+        return ticket.wait()
 
 
 class _Group(object):

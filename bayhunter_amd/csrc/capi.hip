@@ -31,7 +31,10 @@ int fail_arg(const char *what)
 }
 }  // namespace
 // shared with chains.cpp (host-only translation unit)
-namespace bh { int fail_arg_(const char *what) { g_err = what; return BH_ERR_ARG; } }
+namespace bh {
+int fail_arg_(const char *what) { g_err = what; return BH_ERR_ARG; }
+int fail_hip_(int e, const char *what) { return fail_hip((hipError_t)e, what); }     // evalplan.hip
+}
 namespace {
 #define BH_HIP(call)                                          \
     do {                                                      \

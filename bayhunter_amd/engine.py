@@ -11,22 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-
-ORDER_MIN = 8192         # below this one wave works on one search (64/32-lane teams): order is irrelevant
-
-SWD_REFS = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
-RF_REFS = {'prf': 0, 'seis': 0, 'srf': 1}
-
-
-def rf_obsparams(obsx, ref='prf'):
-    """fsamp, tshft, nsamp from the observed time axis (src/rfmini_modrf.py:41-62)."""
-    obsx = np.asarray(obsx, dtype=np.float64)
-    steps = np.unique(np.round(np.diff(obsx), 4))
-    if steps.size != 1:
-        raise ValueError("receiver-function target '%s': the time axis must be uniformly sampled" % ref)
-    fsamp = 1. / float(steps[0])
-    nsamp = 2.**int(np.ceil(np.log2(obsx.size * 2)))       # a float, like the reference's
-    return fsamp, float(-obsx[0]), nsamp
+from .layout import ORDER_MIN, RF_REFS, SWD_REFS, RfSpec, RowLayout, SwdSpec, rf_obsparams  # noqa: F401 (re-exported)
 
 
 class DeviceModels(object):
@@ -46,36 +31,6 @@ class DeviceModels(object):
         self.order = order
 
 
-class SwdSpec(object):
-    def __init__(self, ref, periods, mode=1, flsph=0):
-        if ref not in SWD_REFS:
-            raise ReferenceError("no dispersion forward model for ref '%s'" % ref)
-        self.ref = ref
-        self.iwave, self.igr = SWD_REFS[ref]
-        self.obsx = np.ascontiguousarray(periods, dtype=np.float64)
-        # more than NP = 60 periods (surfdisp96.f:62): solve on 60 evenly spaced periods over the same
-        # span and interpolate linearly to the observed ones, like SurfDisp (surf96_modsw.py:35-43,
-        # 106-122); ForwardEngine does the interpolation on the device
-        self.resample = self.obsx.size > _lib.MAX_PERIODS
-        self.periods = np.linspace(self.obsx.min(), self.obsx.max(), _lib.MAX_PERIODS) if self.resample \
-            else self.obsx
-        self.mode, self.flsph = int(mode), int(flsph)
-
-
-class RfSpec(object):
-    def __init__(self, ref, obsx, gauss=1.0, p=6.4, nsv=None, wtype=None):
-        if wtype is None:
-            if ref not in RF_REFS:
-                raise ReferenceError("no receiver-function forward model for ref '%s'" % ref)
-            self.waveno = RF_REFS[ref]
-        else:
-            self.waveno = {'P': 0, 'SV': 1}[wtype]
-        self.ref = ref
-        self.obsx = np.ascontiguousarray(obsx, dtype=np.float64)
-        self.fsamp, self.tshft, self.nsamp = rf_obsparams(self.obsx, ref)
-        self.gauss, self.p, self.nsv = float(gauss), float(p), nsv
-
-
 class ForwardEngine(object):
     """All targets of a joint inversion for a batch of models in (at most) two launches.
 
@@ -91,45 +46,14 @@ class ForwardEngine(object):
             raise _lib.BayHunterAmdError("no HIP device visible to torch; there is no CPU fallback")
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
             else torch.device(device)
-        self.swd = list(swd)
-        self.rf = list(rf)
-        if len(self.swd) > _lib.MAX_TARGETS:
-            raise ValueError("too many SWD targets")
-        off = 0
-        self.slices = []
-        for sp in self.swd:
-            self.slices.append(slice(off, off + sp.obsx.size))
-            off += sp.obsx.size
-        rf_off = []
-        for r in self.rf:
-            rf_off.append(off)
-            self.slices.append(slice(off, off + r.obsx.size))
-            off += r.obsx.size
-        self.ncols = off
-        per_off = 0
-        self._tg = (_lib.SwdTarget * max(1, len(self.swd)))()
-        pers = []
-        self._interp = []                                  # (user slice, scratch offset, device tables)
-        for t, sp in enumerate(self.swd):
-            koff = self.slices[t].start
-            if sp.resample:                                # the kernel writes behind the visible columns
-                koff = off
-                off += sp.periods.size
-            self._tg[t] = _lib.SwdTarget(sp.iwave, sp.igr, sp.mode, sp.flsph, sp.periods.size,
-                                         per_off, koff, 0)
-            if sp.resample:
-                self._interp.append((self.slices[t], koff, self._interp_tables(sp)))
-            pers.append(sp.periods)
-            per_off += sp.periods.size
-        self._rfp = []
-        for r, o in zip(self.rf, rf_off):
-            self._rfp.append(_lib.RfParams(r.p, r.gauss, r.fsamp, r.tshft,
-                                           -1.0 if r.nsv is None else float(r.nsv),
-                                           int(r.nsamp), r.waveno, r.obsx.size, o))
-        self.row = off
+        self.layout = lay = RowLayout(swd, rf)
+        self.swd, self.rf = lay.swd, lay.rf
+        self.slices, self.ncols, self.row = lay.slices, lay.ncols, lay.row
+        self._tg, self._rfp = lay.tg, lay.rfp
+        # (user slice, scratch offset, device tables) of every target with more than 60 periods
+        self._interp = [(sl, koff, self._interp_tables(sp)) for _, sl, koff, sp in lay.resampled]
         with torch.cuda.device(self.device):
-            self.periods = torch.from_numpy(
-                np.concatenate(pers) if pers else np.zeros(1)).to(self.device)
+            self.periods = torch.from_numpy(lay.periods).to(self.device)
         # per launch stream (batches may be in flight on several streams at once, chains.GpuEvaluator):
         self._ws = {}            # workspace of bh_swd_batch
         self._side = {}          # side stream: RF back-fills the SIMDs the SWD tail leaves idle

@@ -236,9 +236,11 @@ class JointTarget(object):
         self.proposalmisfits = self.get_misfits()
 
     # ------------------------------------------------------------------ batched, on the GPU
-    def _build_batch(self):
-        import torch
-        from .engine import ForwardEngine, RfSpec, SwdSpec
+    def batch_layout(self):
+        """What a batched evaluation needs besides device memory (no torch, no device): the row layout of
+        the forward kernels (layout.RowLayout), the likelihood descriptors, and the observed data / auxiliary
+        arrays (scaled errors, dense R^-1) as host arrays."""
+        from .layout import RfSpec, RowLayout, SwdSpec
         swd, rf, order = [], [], []
         for t in self.targets:
             p = t.moddata.plugin
@@ -252,9 +254,9 @@ class JointTarget(object):
                                  p.modelparams['nsv'], wtype=p.modelparams['wtype']))
             else:
                 raise TypeError("evaluate_batch supports the built-in SurfDisp / RFminiModRF plugins")
-        eng = ForwardEngine(swd=swd, rf=rf)
-        slices = [eng.slices[i if kind == 'swd' else len(swd) + i] for kind, i in order]
-        yobs = np.zeros(eng.row)
+        lay = RowLayout(swd, rf)
+        slices = [lay.slices[i if kind == 'swd' else len(swd) + i] for kind, i in order]
+        yobs = np.zeros(lay.row)
         aux, desc = [], (_lib.LikeTarget * self.ntargets)()
         aux_off = 0
         for n, (t, sl) in enumerate(zip(self.targets, slices)):
@@ -270,12 +272,24 @@ class JointTarget(object):
             if a is not None:
                 aux.append(np.asarray(a, dtype=np.float64))
                 aux_off += aux[-1].size
+        return dict(layout=lay, desc=desc, nflags=max(1, len(swd)), yobs=yobs,
+                    aux=np.ascontiguousarray(np.concatenate(aux) if aux else np.zeros(1), dtype=np.float64))
+
+    def _build_batch(self):
+        import torch
+        from .engine import ForwardEngine
+        bl = self.batch_layout()
+        eng = ForwardEngine(swd=bl['layout'].swd, rf=bl['layout'].rf)
         dev = eng.device
-        self._batch = dict(
-            eng=eng, desc=desc, nflags=max(1, len(swd)),
-            yobs=torch.from_numpy(yobs).to(dev),
-            aux=torch.from_numpy(np.concatenate(aux) if aux else np.zeros(1)).to(dev))
+        self._batch = dict(eng=eng, desc=bl['desc'], nflags=bl['nflags'],
+                           yobs=torch.from_numpy(bl['yobs']).to(dev), aux=torch.from_numpy(bl['aux']).to(dev))
         return self._batch
+
+    def eval_plan(self, max_models, Lmax):
+        """An evaluation plan of the library for batches of up to `max_models` proposals of at most `Lmax`
+        layers (evalplan.EvalPlan: proposals -> (logL, misfits) in one C call, no torch)."""
+        from .evalplan import EvalPlan
+        return EvalPlan(self.batch_layout(), max_models, Lmax, use_mfma=self.use_mfma)
 
     def evaluate_batch(self, H, VP=None, VS=None, nlay=None, noise=None, RHO=None, stream=None):
         """Many models at once: `evaluate_batch(models, noise=...)` with resident

@@ -328,6 +328,48 @@ int  bh_chains_set_rng(bh_chain_pool *pool, int chain, const unsigned *key, int 
 int  bh_chains_draw(bh_chain_pool *pool, int chain, int kind, double a, double b, int n,
                     double *out);
 
+/* ---- evaluation plan: a batch of proposals -> (logL, misfits) in one call ----------------- */
+/* What the sampler does with the proposals of one iteration (reference: one JointTarget.evaluate per
+ * chain and iteration, src/SingleChain.py:545-552, src/Targets.py:314-347): copy them to the device,
+ * order them, run every dispersion target, every receiver function and the fused likelihood, copy
+ * 8*(ntargets+2) bytes per model back.  A plan owns everything that needs -- device buffers, pinned host
+ * staging, its own two streams (the receiver functions back-fill the tail of the dispersion kernel),
+ * events, sort scratch -- so that bh_eval_submit is a handful of asynchronous HIP calls and nothing else:
+ * no allocation, no synchronisation, no interpreter in the loop.
+ *
+ *   bh_eval_create(...)                         once per (targets, pool size); on the current device
+ *   bh_eval_buffers(plan, &packed, &nlay, &noise, &chain, &results)   pinned host memory of the plan
+ *   { bh_chains_propose(pool, Lmax, packed, nlay, noise, chain, &count);   writes the staging block
+ *     bh_eval_submit(plan, count);                                          asynchronous
+ *     bh_eval_wait(plan, NULL);                                             results[] is valid
+ *     bh_chains_accept(pool, results, results + count); }
+ *
+ * Staging layout (max_models rows each): packed [rows][4][Lmax] doubles (h, vp, vs, rho: model_stride =
+ * 4*Lmax), noise [rows][2*ntargets], nlay [rows] int32, chain [rows] int32 (not sent to the device).
+ * results: logL[count] followed by misfits[count][ntargets+1] of the last submission.
+ * row / out_off / off describe one output row exactly as for bh_swd_batch, bh_rf_batch and
+ * bh_likelihood_batch; periods, yobs[row] and aux[naux] are HOST arrays, copied once.  A dispersion target
+ * with more than 60 observed periods is solved on its 60 periods (columns out_off .. behind the visible
+ * ones) and interpolated to obsx[n_dst] at columns dst_off .. with numpy.interp's formula
+ * (surf96_modsw.py:35-43,106-122): one bh_eval_interp per such target. */
+typedef struct bh_eval_plan bh_eval_plan;
+typedef struct bh_eval_interp {
+    int target;          /* index into the dispersion targets                                  */
+    int dst_off, n_dst;  /* visible columns of the target in the output row, number of obsx    */
+    int _pad;
+    const double *obsx;  /* observed periods [n_dst] (host)                                    */
+} bh_eval_interp;
+int  bh_eval_create(int max_models, int Lmax, int row, int nswd, const bh_swd_target *swd,
+                    const double *periods, int nperiods, int nrf, const bh_rf_params *rf, int ntargets,
+                    const bh_like_target *like, int nflags, const double *yobs, const double *aux,
+                    size_t naux, int ninterp, const bh_eval_interp *interp, int use_mfma,
+                    bh_eval_plan **plan);
+void bh_eval_destroy(bh_eval_plan *plan);
+int  bh_eval_buffers(bh_eval_plan *plan, double **packed, int **nlay, double **noise, int **chain,
+                     double **results);
+int  bh_eval_submit(bh_eval_plan *plan, int count);
+int  bh_eval_wait(bh_eval_plan *plan, int *count);   /* blocks until the last submission has landed */
+
 /* ---- plumbing for hosts without their own device allocator ------------------------------ */
 int bh_malloc(void **dptr, size_t bytes);
 int bh_free(void *dptr);

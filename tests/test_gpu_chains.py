@@ -223,3 +223,59 @@ print('rccl ok')
     s.close()
     r = subprocess.run([sys.executable, '-c', code, str(port)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- the evaluation plan of the library (bh_eval_*): what GpuEvaluator submits a batch through --------
+def _random_batch(B, Lmax, T, seed, ragged=(2, 12)):
+    from bayhunter_amd.synthetic import draw_models
+    H, VP, VS, RHO, nl = draw_models(B, ragged, seed=seed, sorted_vs=False, Lmax=Lmax)
+    rs = np.random.RandomState(seed + 1)
+    noise = np.column_stack([f(B) for _ in range(T) for f in (lambda n: rs.uniform(0.0, 0.9, n), lambda n: rs.uniform(0.005, 0.05, n))])
+    return np.stack([H, VP, VS, RHO], axis=1), nl, np.ascontiguousarray(noise)
+
+
+@pytest.mark.parametrize('B', [5, 700, 20000])
+def test_eval_plan_equals_the_engine_path(B):
+    """One bh_eval_submit = ForwardEngine.run + likelihood_batch through torch, bit for bit: small batches
+    (team kernels), one with more rows than the plan was sized for half of, and one large enough for the
+    processing order (device radix sort instead of torch.argsort: results land in the caller's rows either
+    way).  Receiver-function target with the dense Gaussian covariance, i.e. the matrix-core path."""
+    import torch
+    from chain_scenario import joint_target
+    joint = joint_target(DATA)
+    joint.set_target_covariance([True, True], [0.0, 0.9], 1e-5)
+    Lmax, T = 12, joint.ntargets
+    packed, nl, noise = _random_batch(B, Lmax, T, seed=B)
+    plan = joint.eval_plan(B + 7, Lmax)
+    for rep in range(2):                                   # a plan is reused iteration after iteration
+        plan.packed[:B], plan.nlay[:B], plan.noise[:B] = packed, nl, noise
+        plan.submit(B)
+        logL, mis = (a.copy() for a in plan.wait())
+        wl, wm = joint.evaluate_batch(packed[:, 0], packed[:, 1], packed[:, 2], nl, noise, RHO=packed[:, 3])
+        torch.cuda.synchronize()
+        assert np.array_equal(logL, wl.cpu().numpy(), equal_nan=True), (B, rep)
+        assert np.array_equal(mis, wm.cpu().numpy(), equal_nan=True), (B, rep)
+        assert logL.shape == (B,) and mis.shape == (B, T + 1) and np.isfinite(logL).mean() > 0.9
+        packed, nl, noise = _random_batch(B, Lmax, T, seed=B + 100)
+    plan.submit(0)                                         # an iteration without a valid proposal
+    assert plan.wait()[0].shape == (0,)
+    plan.close()
+
+
+def test_eval_plan_more_than_60_periods_and_swd_only():
+    """A dispersion target with 75 observed periods (solved on 60, interpolated on the device by the plan's
+    own kernel) next to an ordinary one, no receiver function: equal to the engine's torch interpolation."""
+    import torch
+    from bayhunter_amd import targets as T
+    x75, x21 = np.linspace(2, 80, 75), np.linspace(1, 41, 21)
+    joint = T.JointTarget([T.RayleighDispersionPhase(x75, np.full(75, 3.5)), T.LoveDispersionGroup(x21, np.full(21, 3.3))])
+    joint.set_target_covariance([True, False], [0.0, 0.3], None)
+    packed, nl, noise = _random_batch(300, 10, 2, seed=9, ragged=(2, 10))
+    plan = joint.eval_plan(300, 10)
+    plan.packed[:], plan.nlay[:], plan.noise[:] = packed, nl, noise
+    plan.submit(300)
+    logL, mis = plan.wait()
+    wl, wm = joint.evaluate_batch(packed[:, 0], packed[:, 1], packed[:, 2], nl, noise, RHO=packed[:, 3])
+    torch.cuda.synchronize()
+    assert np.array_equal(logL, wl.cpu().numpy(), equal_nan=True) and np.array_equal(mis, wm.cpu().numpy(), equal_nan=True)
+    assert np.isfinite(logL).mean() > 0.5

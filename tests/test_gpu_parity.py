@@ -505,7 +505,9 @@ def test_synrf_dropin_returns_all_three_traces(lib, oracle):
             _lib.check(lib.bh_synrf(nsamp, 5.0, 5.0, 6.4, 1.5, 3.1, 0.27, wn, n, z.ctypes.data,
                                     vp.ctypes.data, vs.ctypes.data, rh.ctypes.data, qp.ctypes.data,
                                     qs.ctypes.data, None, None, rf2.ctypes.data))
-            assert np.array_equal(rf, rf2)
+            # (without fz/fr the kernel leaves the unit factor exp(i w t0) out of the spectral ratio, in
+            # which it cancels: same trace up to rounding)
+            assert np.abs(rf - rf2).max() <= 1e-14 * max(1.0, np.abs(rf).max())
 
 
 def test_rf_frequency_cutoff_on_resonant_low_q_models(lib, oracle):
