@@ -338,15 +338,15 @@ struct TeamSrc {
 // Diagnostic build only (-DBH_TEAM_PROFILE, tools/team_phase_profile.py): shader-clock cycles per
 // phase of the 64-lane team loop, summed over all searches; read back with bh_debug_team_profile.
 #if defined(BH_TEAM_PROFILE)
-__device__ unsigned long long g_team_prof[16];
-#define BH_TP_DECL unsigned long long tp_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_t0_ = clock64(), tp_t1_
+__device__ unsigned long long g_team_prof[20];
+#define BH_TP_DECL unsigned long long tp_[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_t0_ = clock64(), tp_t1_
 #define BH_TP(i) (tp_t1_ = clock64(), tp_[i] += tp_t1_ - tp_t0_, tp_t0_ = tp_t1_)
 #define BH_TP_COUNT(i, n) (tp_[i] += (n))
 #define BH_TP_FLUSH(rounds)                                                                  \
     if (threadIdx.x == 0) {                                                                  \
-        for (int i_ = 0; i_ < 14; i_++) atomicAdd(&g_team_prof[i_], tp_[i_]);                \
-        atomicAdd(&g_team_prof[14], (unsigned long long)(rounds));                           \
-        atomicAdd(&g_team_prof[15], 1ull);                                                   \
+        for (int i_ = 0; i_ < 18; i_++) atomicAdd(&g_team_prof[i_], tp_[i_]);                \
+        atomicAdd(&g_team_prof[18], (unsigned long long)(rounds));                           \
+        atomicAdd(&g_team_prof[19], 1ull);                                                   \
     }
 #else
 #define BH_TP_DECL
@@ -683,6 +683,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
                 }
                 R = swd_teamw_round(S, tg, perl, cap, nxt);
                 nt = R.nt;
+                BH_TP(13);
                 swd_teamw_trial(R, S, wl < nt ? wl : 0, &mc, &mom);
                 if (lane < nt) { tcl[lane] = mc; toml[lane] = mom; }
             }
@@ -704,6 +705,9 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;
             if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
             if (cap < 1) cap = 1;
+// (lanes of a wave hold the layers of few trials.  Layer-major -- a wave holding one or two layers for
+            // many trials, so that it runs one branch of `var` instead of both -- was measured: 1 % faster on 15
+            // layers x 512 lanes, 8 % slower on 5 layers x 64 lanes; same-box A/B, profiles/r03_ab_team.txt)
             ja = (cap > 1 && nlm > 0) ? lane / nlm : 0;
             ra = lane - ja * nlm;
             // this lane's layer and the half-space, read from the shared copy once (after a possible
@@ -729,8 +733,14 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         __syncthreads();
         BH_TP(2);
         if (tg.iwave == 2) {
-            const double del = swd_teamw_chain_quad(lay, half, S, qc, qom, mats + (long)(qvalid ? jq : 0) * nlm * SWD_MAT);
-            if (qvalid && (wl & 3) == 0) dels[jq] = del;
+            // A wave chains 16 trials (one per quad) in the time it chains one: the trials fill waves 0, 1, ...
+            // and a wave without any skips the chain -- with eight waves on four SIMDs an idle wave walking
+            // through the chain (on trial 0, as an invalid quad does) took issue slots from the wave that
+            // shares its SIMD: 8 700 instead of 5 700 cycles per round on 15 layers (team512).
+            if (W == 1 || 16 * wave < nt) {
+                const double del = swd_teamw_chain_quad(lay, half, S, qc, qom, mats + (long)(qvalid ? jq : 0) * nlm * SWD_MAT);
+                if (qvalid && (wl & 3) == 0) dels[jq] = del;
+            }
         } else if (lane < nt) {
             dels[lane] = swd_teamw_chain_one(lay, 1, S, mc, mom, mats + (long)lane * nlm * SWD_MAT);
         }
@@ -748,6 +758,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
                 goL = __ballot(innode && nd.go == SWD_GO_LEFT);
                 goR = __ballot(innode && nd.go == SWD_GO_RIGHT);
             }
+            BH_TP(14);
 #if defined(BH_TEAM_PROFILE)
             TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR, tp_, &tp_t0_};
 #else
@@ -908,7 +919,7 @@ extern "C" int bh_debug_team_profile(unsigned long long *out, int reset)
 {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_team_prof), sizeof(g_team_prof)) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[20] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_team_prof), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;

@@ -218,6 +218,39 @@ enum { SWD_TEAMW_NT = 64 };       // max trials per round (one per lane of the c
 
 enum { SWD_MAT = 30 };            // doubles per stored layer matrix: 5 columns x 6 (5 used, 16-byte aligned)
 
+// floor(log2(x)) for x >= 1
+BH_DEV int swd_ilog2(int x) { return 31 - __builtin_clz((unsigned)x); }
+
+// Cell i of a bracketing scan that starts at `base`: its base b_i and its end c_i = b_i + dc, where
+// b_0 = base and b_{i+1} = c_i -- the reference adds dc once per step (surfdisp96.f:448-452), and so
+// must every replay, rounding included.  But those additions do not round while the values stay in one
+// binade: dc = dble(0.005) carries 24 significant bits down to 2^-31 and a velocity in [2^e, 2^(e+1))
+// has an ulp of 2^(e-52) <= 2^-31, so x + dc is exactly representable unless it reaches 2^(e+1); then
+// b_i = base + i dc and c_i = base + (i+1) dc hold exactly (the products are exact: i + 1 <= 64).  A
+// scan that crosses a power of two (2 or 4 km/s) takes the additions one by one from the start.
+BH_DEV void swd_scan_cell(double base, int i, double *b, double *cn)
+{
+    const double dc = (double)0.005f;
+    const double hi = base + (double)(i + 1) * dc;
+#if defined(BH_HOSTSIM)
+    long long ub, uh;
+    __builtin_memcpy(&ub, &base, 8); __builtin_memcpy(&uh, &hi, 8);
+    const bool same_binade = ub > 0 && ((ub ^ uh) >> 52) == 0;
+#else
+    const int eb = __double2hiint(base), eh = __double2hiint(hi);
+    const bool same_binade = eb > 0 && ((eb ^ eh) >> 20) == 0;       // sign and exponent bits agree
+#endif
+    if (same_binade) {
+        *b = base + (double)i * dc;
+        *cn = hi;
+        return;
+    }
+    double x = base, c = base + dc;
+    for (int n = i; n > 0; n--) { x = c; c = x + dc; }
+    *b = x;
+    *cn = c;
+}
+
 // ---- the plan of a round ----------------------------------------------------------------------
 // Slot 0 is the evaluation the search is waiting for; the rest is speculation, most valuable first:
 //   bracketing (ST_A / ST_B)   the scan continues on the grid: scan trial i = base + (i+1) dc by
@@ -372,8 +405,7 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
         // node j of the bisection tree in level order: level l = floor(log2(j+1)), position p in the
         // level; walk down from the pending trial, a bit of p per level (0: the value there has the
         // sign of del2 -> c2 = c3; 1: c1 = c3), taking midpoints exactly like nevill (:583,:661)
-        int l = 1;
-        while ((2 << l) - 1 <= j) l++;
+        const int l = swd_ilog2(j + 1);
         const int pth = j + 1 - (1 << l);
         double lo = S.c1, mid = S.ceval, hi = S.c2;
         for (int b = l - 1; b >= 0; b--) {
@@ -392,22 +424,8 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
     // base_0 = base, base_{n+1} = c_n = base_n + dc by repeated addition.  The scan stops at the first
     // base outside [cc, cfail) (swd_control: "c1 < cm or c1 >= betmx + dc -> no root"); the bases
     // increase, so it is enough to look at the first and at this cell's
-    double b = g.base, cn = g.base + dc;
-    int n = i;
-    for (; n >= 4; n -= 4) {
-        const double c1 = cn + dc, c2 = c1 + dc, c3 = c2 + dc;
-        b = c3;
-        cn = c3 + dc;
-    }
-    if (n & 2) {
-        const double c1 = cn + dc;
-        b = c1;
-        cn = c1 + dc;
-    }
-    if (n & 1) {
-        b = cn;
-        cn = b + dc;
-    }
+    double b, cn;
+    swd_scan_cell(g.base, i, &b, &cn);
     const bool ok = !(g.base < S.cc) && !(b >= S.cfail);
     *c = ok ? (mid ? 0.5 * (b + cn) : cn) : __builtin_nan("");
 }
@@ -429,8 +447,7 @@ template <class Del>
 BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const Del &del, int j)
 {
     const double pct = (double)0.01f;
-    int l = 0;
-    while ((2 << l) - 1 <= j) l++;
+    const int l = swd_ilog2(j + 1);
     const int pth = j + 1 - (1 << l);
     TeamwNode n;
     n.c1 = S.c1; n.d1 = S.del1; n.c2 = S.c2; n.d2 = S.del2;
@@ -587,6 +604,7 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
                 j = last;
                 vals.count(12, lev);
             }
+            vals.probe(15);
         }
         if (S.st == SWD_ST_B && S.idir > 0 && R.ngrp > 0 && (R.nhalf == 0 || j > R.nhalf)) {
             const TeamwScan &g = swd_teamw_group(R, j);

@@ -57,6 +57,7 @@ def _wrap_hostsim(hs):
     hs.hs_rf.restype = C.c_int
     hs.hs_rf.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int,
                          C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp]
+    hs.hs_scan_cell.argtypes = [C.c_int, dp, C.POINTER(C.c_int), dp, dp]
     hs.hs_sincos.argtypes = [C.c_int, dp, dp, dp]
     hs.hs_exp.argtypes = [C.c_int, dp, dp]
 
@@ -96,6 +97,15 @@ def _wrap_hostsim(hs):
                      fsamp, tshift, -1.0 if nsv is None else nsv, waveno, nout,
                      out.ctypes.data_as(dp))
             return out
+
+        @staticmethod
+        def scan_cell(base, cell):
+            base = np.ascontiguousarray(base, dtype=np.float64)
+            cell = np.ascontiguousarray(cell, dtype=np.int32)
+            b, cn = np.zeros_like(base), np.zeros_like(base)
+            hs.hs_scan_cell(base.size, base.ctypes.data_as(dp), cell.ctypes.data_as(C.POINTER(C.c_int)),
+                            b.ctypes.data_as(dp), cn.ctypes.data_as(dp))
+            return b, cn
 
         @staticmethod
         def sincos(x):

@@ -266,6 +266,12 @@ extern "C" int hs_rf(int nlay, const double *h, const double *vp, const double *
                                 waveno, nout, rf);
 }
 
+// swd_scan_cell (swd_team.h): closed form against the reference's repeated addition
+extern "C" void hs_scan_cell(int n, const double *base, const int *cell, double *b, double *cn)
+{
+    for (int k = 0; k < n; k++) bh::swd_scan_cell(base[k], cell[k], &b[k], &cn[k]);
+}
+
 // accuracy probes for bh_math.h (tests/test_hostsim.py::test_math_accuracy)
 extern "C" void hs_sincos(int n, const double *x, double *s, double *c)
 {

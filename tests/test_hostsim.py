@@ -119,6 +119,27 @@ def test_rf_every_transform_length(oracle, hostsim, nsamp):
         assert np.all(np.isfinite(r)) and np.abs(a - r).max() <= 1e-12 * max(1.0, np.abs(a).max())
 
 
+def test_scan_cells_in_closed_form_equal_repeated_addition(hostsim):
+    """swd_scan_cell gives cell i of a bracketing scan as base + i dc, base + (i+1) dc when the scan stays
+    inside one binade, where the reference's repeated addition of dc = dble(0.005) (surfdisp96.f:448-452)
+    does not round; the bits must be those of the repeated addition for every start value, also across
+    powers of two, for fp32-valued starts (the first period's) and for values far outside any model."""
+    rs = np.random.RandomState(3)
+    n = 400000
+    base = np.concatenate([rs.uniform(0.05, 9.0, n), rs.uniform(0.3, 5.3, n).astype(np.float32).astype(np.float64),
+                           rs.choice([0.5, 1., 2., 4., 8.], n) - 0.35 * rs.rand(n) ** 2,
+                           np.ldexp(rs.rand(n), rs.randint(-30, 10, n)), [0.0, -1.0, np.nan, np.inf]])
+    cell = rs.randint(0, 64, base.size)
+    dc = np.float64(np.float32(0.005))
+    x, c = base.copy(), base + dc
+    for k in range(1, 64):
+        step = cell >= k
+        x = np.where(step, c, x)
+        c = np.where(step, x + dc, c)
+    b, cn = hostsim.scan_cell(base, cell)
+    assert np.array_equal(b, x, equal_nan=True) and np.array_equal(cn, c, equal_nan=True)
+
+
 def test_rf_frequency_cutoff_on_resonant_low_q_models(oracle, hostsim):
     """The kernel zero-fills the frequencies whose Gauss-filter weight is below 3e-19 (rf_host.h: 213 of
     257 at a = 1, 5 Hz); the reference computes all of them.  What is dropped is cutoff x |R/Z| per bin,
