@@ -308,7 +308,7 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     // Which kernel: each form k has a latency lat_k (one search, chip mostly idle) and a saturation
     // rate thr_k (searches per ms with every SIMD busy); a call with s searches costs about
     // max(lat_k, s / thr_k).  Table measured on MI355X (256 CUs) for 21 periods, Rayleigh phase
-    // (profiles/r02_team_widths.txt, fitted by tools/fit_forms.py; relative order is what matters), by deepest model of the batch;
+    // (profiles/r03_team_widths.txt, fitted by tools/fit_forms.py; relative order is what matters), by deepest model of the batch;
     // thr scales with the CU count.  Wide teams (64 W lanes, speculation across root searches) win up
     // to a few thousand searches, 8-lane teams in the ten-thousands, the lane kernel beyond.
     // bh_swd_set_kernel overrides; BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
@@ -316,15 +316,16 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     const long cus = resident > 0 ? resident / 8 : 256;
     struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
     static const Form forms[8] = {
-        {0,   {3.66, 5.37, 9.93, 14.1, 30.4}, {29257, 16487, 8629, 5815, 3508}},    // lane kernel
-        {8,   {2.28, 3.32, 5.78, 6.73, 12.1}, {6674, 4352, 2469, 1652, 781}},
-        {16,  {1.87, 2.49, 4.72, 5.77, 9.82}, {3986, 2895, 1536, 1196, 978}},
-        {32,  {1.49, 1.89, 2.75, 3.89, 8.75}, {2563, 1994, 1306, 884, 687}},
-        {64,  {0.61, 0.62, 0.98, 1.6, 3.7},   {3366, 2953, 1710, 1032, 836}},
-        {128, {0.51, 0.51, 0.86, 1.1, 2.2},   {1959, 1624, 961, 692, 476}},
-        {256, {0.43, 0.43, 0.68, 0.87, 1.5},  {1241, 1089, 680, 518, 397}},
-        {512, {0.47, 0.47, 0.65, 0.83, 1.51}, {645, 575, 414, 324, 233}},
+        {0,   {3.8, 5.4, 9.92, 14.2, 31.2},   {28494, 16804, 8495, 5721, 3519}},   // lane kernel
+        {8,   {2.37, 3.31, 5.9, 6.74, 11.9},  {6620, 4323, 2456, 1646, 782}},
+        {16,  {1.94, 2.45, 4.76, 5.77, 10.3}, {3991, 2869, 1533, 1191, 972}},
+        {32,  {1.51, 1.85, 2.74, 3.9, 8.86},  {2554, 1992, 1301, 880, 687}},
+        {64,  {0.59, 0.59, 0.95, 1.59, 3.66}, {3475, 3041, 1742, 1038, 841}},
+        {128, {0.49, 0.48, 0.81, 1.05, 2.12}, {2047, 1669, 1082, 795, 553}},
+        {256, {0.42, 0.42, 0.66, 0.85, 1.46}, {1280, 1119, 728, 557, 438}},
+        {512, {0.42, 0.42, 0.57, 0.7, 1.18},  {728, 653, 477, 385, 289}},
     };
+
     const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
     bool team = false;
     int width = 64, team_resident = resident;
