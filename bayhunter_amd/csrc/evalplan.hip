@@ -196,8 +196,13 @@ int bh_eval_create(int max_models, int Lmax, int row, int nswd, const bh_swd_tar
     if ((p->like_bytes && hipMalloc(&p->like_ws, p->like_bytes) != hipSuccess) ||
         (p->swd_bytes && hipMalloc(&p->swd_ws, p->swd_bytes) != hipSuccess))
         return bail(bh::fail_hip_((int)hipErrorOutOfMemory, "hipMalloc(workspaces)"));
-    if (hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+    // The receiver-function kernel only back-fills the draining tail of the dispersion kernel when the two
+    // streams differ in priority: two plain streams behaved like one (68.1 vs 66.0 ms per 524 288-model step,
+    // tools/prio_exp.py), apparently sharing a hardware queue.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&p->st, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess)
