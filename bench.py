@@ -226,6 +226,21 @@ def launch_ranks(args):
     sys.stdout.flush()
 
 
+class stdout_to_stderr(object):
+    """File descriptor 1 points to stderr inside the block: the rendezvous of a backend may chat on stdout
+    (gloo: "[Gloo] Rank 0 is connected to ..."), and stdout carries exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 # ------------------------------------------------------------------------------------ chain pool
 def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
     """End-to-end sampler on top of the timed path (not part of `value`): a lock-step pool of
@@ -453,9 +468,10 @@ def main():
         seen = [None] * world
         if world > 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('gloo')
-            dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
-            dist.destroy_process_group()
+            with stdout_to_stderr():
+                dist.init_process_group('gloo')
+                dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
+                dist.destroy_process_group()
         else:
             seen = [(rank, local_rank, os.getpid())]
         if rank == 0:
@@ -496,7 +512,8 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend)
+        with stdout_to_stderr():
+            dist.init_process_group(backend)
         if dist.get_world_size() != args.gpus:
             sys.exit('bench.py: process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
     ranks = Ranks(world, backend, dev)

@@ -27,8 +27,8 @@ def _run(args, env=None, timeout=600):
 
 def _line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, r.stdout          # ONE json line, whatever the number of ranks
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout          # ONE line on stdout, the JSON, whatever the number of ranks
     return json.loads(lines[0])
 
 

@@ -44,4 +44,6 @@ def test_c_consumer_runs_tutorial_model(lib, golden):
     cg2 = np.array([float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith('cg2 ')])
     rf2 = np.array([float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith('rf2 ')])
     assert 'err2 0' in r.stdout and 'synrf_cwrap returned 1' in r.stdout
-    assert np.array_equal(cg2, cg) and np.array_equal(rf2, rf)
+    # (synrf_cwrap also returns fz / fr: the kernel form that keeps the unit factor exp(i w t0), which cancels
+    # in the receiver function -- equal to the call without them up to rounding)
+    assert np.array_equal(cg2, cg) and np.abs(rf2 - rf).max() <= 1e-14 * max(1.0, np.abs(rf).max())

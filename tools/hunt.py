@@ -1,4 +1,7 @@
-"""Run an inversion the way the reference's tutorial/tutorialhunt.py does -- BayHunter config.ini,
+"""MEASUREMENT TOOLING, outside the scope table of SURVEY section 8 (the reference's command-line / config
+layer is not rebuilt): a convenience for running whole inversions on the GPU box.
+
+Run an inversion the way the reference's tutorial/tutorialhunt.py does -- BayHunter config.ini,
 observed data files -- on the lock-step chain pool, and write the reference's result files.
 
     python tools/hunt.py tutorial/config.ini --target rdispph=obs/st3_rdispph.dat \\
