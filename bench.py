@@ -226,19 +226,23 @@ def launch_ranks(args):
     sys.stdout.flush()
 
 
-class stdout_to_stderr(object):
-    """File descriptor 1 points to stderr inside the block: the rendezvous of a backend may chat on stdout
-    (gloo: "[Gloo] Rank 0 is connected to ..."), and stdout carries exactly one JSON line."""
+_REAL_STDOUT = None
 
-    def __enter__(self):
+
+def claim_stdout():
+    """stdout carries exactly ONE line, the JSON.  Libraries chat on file descriptor 1 -- gloo's "[Gloo] Rank 0
+    is connected to ...", RCCL's version banner at the first collective -- so a rank points descriptor 1 at
+    stderr for its whole life and keeps the real stdout for `emit`."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
         sys.stdout.flush()
-        self.saved = os.dup(1)
+        _REAL_STDOUT = os.dup(1)
         os.dup2(2, 1)
 
-    def __exit__(self, *exc):
-        sys.stdout.flush()
-        os.dup2(self.saved, 1)
-        os.close(self.saved)
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + '\n').encode())
 
 
 # ------------------------------------------------------------------------------------ chain pool
@@ -274,11 +278,12 @@ def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
 class Ranks(object):
     """The process group as the timed region sees it (a no-op for one rank)."""
 
-    def __init__(self, world, backend, device_index):
+    def __init__(self, world, backend, device_index, active=None):
         self.world, self.backend, self.dev = world, backend, device_index
+        self.active = world > 1 if active is None else active      # a process group exists
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             import torch.distributed as dist
             if self.backend == 'nccl':
                 dist.barrier(device_ids=[self.dev])
@@ -290,7 +295,7 @@ class Ranks(object):
         return max_over_ranks(value, device='cuda' if self.backend == 'nccl' else 'cpu')
 
     def all_floats(self, value):
-        if self.world == 1:
+        if not self.active:
             return [float(value)]
         import torch
         import torch.distributed as dist
@@ -463,21 +468,21 @@ def main():
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU '
                  '(torch.distributed.run --nproc-per-node %d, or plain `python bench.py --gpus %d`)'
                  % (args.gpus, world, args.gpus, args.gpus))
+    claim_stdout()                               # from here on this process is a rank: stdout = the one JSON line
     if args.probe_ranks:                         # launcher / rendezvous check without a GPU (tests)
         import torch.distributed as dist
         seen = [None] * world
         if world > 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            with stdout_to_stderr():
-                dist.init_process_group('gloo')
-                dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
-                dist.destroy_process_group()
+            dist.init_process_group('gloo')
+            dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
+            dist.destroy_process_group()
         else:
             seen = [(rank, local_rank, os.getpid())]
         if rank == 0:
-            print(json.dumps({"probe": True, "n_gpus": world, "ranks_seen": len(set(s[0] for s in seen)),
+            emit(json.dumps({"probe": True, "n_gpus": world, "ranks_seen": len(set(s[0] for s in seen)),
                               "local_ranks": sorted(s[1] for s in seen), "pids": len(set(s[2] for s in seen)),
-                              "launcher": os.environ.get('BH_BENCH_LAUNCHER', 'external' if world > 1 else None)}))
+                             "launcher": os.environ.get('BH_BENCH_LAUNCHER', 'external' if world > 1 else None)}))
         return
     headline = args.workload == 'joint10' and args.batch is None
     with_configs = headline and not args.no_configs
@@ -510,13 +515,18 @@ def main():
                  '(BH_DIST_BACKEND=gloo allows sharing, for rehearsal only)' % (world, ndev))
     dev = local_rank if ndev >= world else local_rank % ndev
     torch.cuda.set_device(dev)
-    if world > 1:
+    # BH_BENCH_FORCE_DIST=1 (test hook): a one-rank process group, so that the collective branches below run
+    # over RCCL on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get('BH_BENCH_FORCE_DIST'))
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        with stdout_to_stderr():
-            dist.init_process_group(backend)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        dist.init_process_group(backend)
         if dist.get_world_size() != args.gpus:
             sys.exit('bench.py: process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
-    ranks = Ranks(world, backend, dev)
+    ranks = Ranks(world, backend, dev, active=use_dist)
 
     # who is here: every rank's device, gathered over the process group (RCCL with backend nccl)
     props = torch.cuda.get_device_properties(dev)
@@ -525,7 +535,7 @@ def main():
     uuid = getattr(props, 'uuid', None)
     ub = uuid.bytes if uuid is not None and hasattr(uuid, 'bytes') else str(uuid).encode()[:16].ljust(16, b'\0')
     me[2:18] = torch.tensor(list(ub[:16]), dtype=torch.int64)
-    if world > 1:
+    if use_dist:
         me = me.to('cuda' if backend == 'nccl' else 'cpu')
         everyone = [torch.empty_like(me) for _ in range(world)]
         dist.all_gather(everyone, me)
@@ -565,7 +575,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "ranks_seen": len(ranks_seen), "devices_seen": devices_seen, "devices": devices,
-            "per_rank_ms_per_step": per_rank_ms, "dist_backend": backend if world > 1 else None,
+            "per_rank_ms_per_step": per_rank_ms, "dist_backend": backend if use_dist else None,
             "launcher": os.environ.get('BH_BENCH_LAUNCHER', 'external' if world > 1 else None),
             "config": {"workload": workload_label(args.workload, B),
                        "models_per_gpu": B, "sharding": "models block-partitioned over ranks, no data-path collective",
@@ -596,8 +606,8 @@ def main():
             res["configs"] = cfgs
         if world == 1 and headline and not args.no_chain_pool:
             res["chain_pool"] = chain_pool_sample()
-        print(json.dumps(res))
-    if world > 1:
+        emit(json.dumps(res))
+    if use_dist:
         dist.barrier() if backend != 'nccl' else dist.barrier(device_ids=[dev])
         dist.destroy_process_group()
 

@@ -73,6 +73,17 @@ def test_two_ranks_on_one_gpu_over_gloo():
 
 
 @pytest.mark.gpu
+def test_collective_branches_run_over_rccl_with_one_rank():
+    """What an 8-GPU run does between the ranks -- RCCL rendezvous, gather of the ranks' devices, barrier with
+    device_ids, MAX all-reduce and gather of the step times on the device -- executed for real by a one-rank
+    `nccl` process group (the only RCCL configuration a one-GPU box can run)."""
+    d = _line(_run(['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '8192', '--no-cpu-baseline', '--no-chain-pool'],
+                   env=dict(BH_BENCH_FORCE_DIST='1')))
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['devices_seen'] == 1 and d['dist_backend'] == 'nccl'
+    assert len(d['per_rank_ms_per_step']) == 1 and d['value'] > 0
+
+
+@pytest.mark.gpu
 def test_rccl_ranks_are_not_stacked_on_one_gpu():
     import torch
     if torch.cuda.device_count() >= 2:

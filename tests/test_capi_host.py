@@ -92,6 +92,40 @@ def test_fails_loudly_without_device(lib):
         rf.run_model(np.array([5., 0.]), np.array([5., 7.]), np.array([3., 4.]), np.array([2.4, 3.]))
 
 
+def test_eval_plan_refuses_without_a_device_and_validates_arguments(lib):
+    """bh_eval_create: argument errors before any device work; with valid arguments and no GPU the plan is not
+    created (BH_ERR_NO_DEVICE) -- the chain pool's evaluator has no CPU path to fall back to."""
+    import ctypes as C
+    import bayhunter_amd as bh
+    from bayhunter_amd import _lib
+    from bayhunter_amd import targets as T
+    x, t = np.linspace(1, 41, 21), np.linspace(-5, 35, 201)
+    joint = T.JointTarget([T.RayleighDispersionPhase(x, np.full(21, 3.5)), T.PReceiverFunction(t, np.zeros(201))])
+    joint.set_target_covariance([True, True], [0.0, 0.0], None)
+    bl = joint.batch_layout()
+    lay = bl['layout']
+    assert lay.row == 222 and bl['nflags'] == 1 and [d.n for d in bl['desc']] == [21, 201]
+    rfp = (_lib.RfParams * 1)(*lay.rfp)
+    handle = C.c_void_p()
+
+    def create(rows=8, Lmax=10, nflags=1, ntargets=2):
+        return lib.bh_eval_create(rows, Lmax, lay.row, 1, lay.tg, lay.periods.ctypes.data, lay.periods.size, 1, rfp,
+                                  ntargets, bl['desc'], nflags, bl['yobs'].ctypes.data, bl['aux'].ctypes.data,
+                                  bl['aux'].size, 0, None, 1, C.byref(handle))
+    assert create(rows=0) == _lib.BH_ERR_ARG and create(Lmax=101) == _lib.BH_ERR_ARG
+    assert create(nflags=3) == _lib.BH_ERR_ARG and create(ntargets=0) == _lib.BH_ERR_ARG
+    assert lib.bh_eval_submit(None, 1) == _lib.BH_ERR_ARG and lib.bh_eval_wait(None, None) == _lib.BH_ERR_ARG
+    if bh.device_count() > 0:
+        pytest.skip('a GPU is present: the rest is the GPU tier')
+    assert create() == _lib.BH_ERR_NO_DEVICE and not handle.value
+    with pytest.raises(bh.BayHunterAmdError):
+        joint.eval_plan(8, 10)
+    from bayhunter_amd.chains import ChainPool
+    with pytest.raises(bh.BayHunterAmdError):
+        ChainPool(joint, initparams=dict(iter_burnin=4, iter_main=4), modelpriors=dict(swdnoise_corr=0., rfnoise_corr=0.),
+                  seeds=[1, 2])
+
+
 def test_plugin_contract():
     """ctor (obsx, ref), ref -> (iwave, igr) map, ReferenceError, modelparams keys, obs params
     (reference: surf96_modsw.py:24-66, rfmini_modrf.py:17-62)."""

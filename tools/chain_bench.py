@@ -19,6 +19,9 @@ def main():
     from bayhunter_amd.chains import ChainPool, GpuEvaluator
     import torch
     sizes = [int(a) for a in sys.argv[1:]] or [256, 1024, 4096, 16384]
+    if 'BH_SWD_KERNEL' in os.environ:                      # pin a kernel form (experiments)
+        from bayhunter_amd import _lib
+        _lib.set_swd_kernel(os.environ['BH_SWD_KERNEL'])
     data = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
     case = CASES['tutorial']
     for n in sizes:
