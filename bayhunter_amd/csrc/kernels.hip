@@ -655,7 +655,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     WideSrc src{A, tg, t, lane, nl, 0, b, res};
     SwdState S;
     swd_state_init(S);
-    TeamwNext nxt{-1, -1, 0.0};
+    TeamwNext nxt{-1, -1, 0.0, {-1, -1}, {-1, -1}};
     BH_TP_DECL;
     long rounds = 0;
     bool first = true;
@@ -764,7 +764,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
 #else
             TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR};
 #endif
-            const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
+            const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v, nxt);
             BH_TP(4);
             BH_TP_COUNT(8, used);
             BH_TP_COUNT(9, nt);

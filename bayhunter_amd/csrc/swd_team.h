@@ -280,6 +280,7 @@ struct TeamwScan {                // an entry evaluation (optional) and the scan
     int entry;                    // slot of the entry evaluation (c = base), or -1
     int scan0, stride, nscan;     // scan trial i in slot scan0 + i*stride, i < nscan (stride 2: cell
                                   // midpoints in between)
+    int mid0, nmid, midslot;      // stride 1: midpoints of the cells mid0 .. mid0+nmid-1 only, in slots midslot ..
     double base, oms;             // the point the scan steps away from, omega of the scan
 };
 struct TeamwRound {
@@ -294,17 +295,49 @@ struct TeamwRound {
 struct TeamwNext {
     int k, pass;
     double oms;
+    // The cell of its bracketing scan in which the last root search of each pass (first solve / second solve of
+    // a group-velocity pair) found the sign change, -1 before the first one.  A dispersion curve is smooth and
+    // the periods are evenly spaced more often than not, so the next search of the same pass finds its sign
+    // change in that cell or a neighbour: their midpoints -- nevill's first point (surfdisp96.f:583), otherwise a
+    // round of its own with one trial -- ride along with a scan too short for a midpoint per cell.
+    int cell[2], cellp[2];        // the last such cell of each pass and the one before: the prediction extrapolates
 };
-
-// lays one scan group out in slots [first, first + room): entry (if has_entry) + scan
-BH_DEV int swd_teamw_scan_layout(TeamwScan &g, int first, int room, bool has_entry, bool scan_ok)
+// the cell in which the next search of `pass` is expected to find its sign change, or -1
+BH_DEV int swd_teamw_predicted_cell(const TeamwNext &nx, int pass)
 {
-    g.entry = -1; g.scan0 = first; g.stride = 1; g.nscan = 0;
+    const int c0 = nx.cell[pass], c1 = nx.cellp[pass];
+    if (c0 < 0) return -1;
+    const int p = c1 < 0 ? c0 : 2 * c0 - c1;        // (a dispersion curve bends slowly: 70 % within one cell)
+    return p < 0 ? 0 : p;
+}
+#ifndef SWD_TEAMW_NMID
+#define SWD_TEAMW_NMID 3          // predicted cell and a neighbour on either side
+#endif
+
+// lays one scan group out in slots [first, first + room): entry (if has_entry) + scan.  want_cell: the cell
+// (counted from this scan's first one) in which the sign change is expected, or < 0.
+BH_DEV int swd_teamw_scan_layout(TeamwScan &g, int first, int room, bool has_entry, bool scan_ok, int want_cell = -1)
+{
+    g.entry = -1; g.scan0 = first; g.stride = 1; g.nscan = 0; g.mid0 = 0; g.nmid = 0; g.midslot = 0;
     if (room <= 0) return first;
     if (has_entry) { g.entry = first; g.scan0 = first + 1; room--; }
     if (!scan_ok || room <= 0) return g.scan0;
-    g.stride = room >= SWD_TEAMW_MIDROOM ? 2 : 1;
-    g.nscan = (room + g.stride - 1) / g.stride;     // stride 2 and odd room: the last cell has no midpoint
+    if (room >= SWD_TEAMW_MIDROOM) {
+        g.stride = 2;
+        g.nscan = (room + 1) / 2;                   // odd room: the last cell has no midpoint
+        return g.scan0 + room;
+    }
+    g.nscan = room;
+#if SWD_TEAMW_NMID > 0
+    // a few midpoints behind the scan slots, if the predicted cell is one of those this scan reaches
+    int lo = want_cell - SWD_TEAMW_NMID / 2;
+    if (lo < 0) lo = 0;
+    const int nscan = room - SWD_TEAMW_NMID;
+    if (want_cell >= 0 && nscan >= SWD_TEAMW_NMID && want_cell < nscan) {
+        if (lo + SWD_TEAMW_NMID > nscan) lo = nscan - SWD_TEAMW_NMID;
+        g.nscan = nscan; g.mid0 = lo; g.nmid = SWD_TEAMW_NMID; g.midslot = g.scan0 + nscan;
+    }
+#endif
     return g.scan0 + room;
 }
 
@@ -314,15 +347,17 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
     const double dc = (double)0.005f;
     TeamwRound R;
     R.nt = 1; R.nhalf = 0; R.ngrp = 0;
-    R.g0.entry = -1; R.g0.scan0 = 1; R.g0.stride = 1; R.g0.nscan = 0; R.g0.base = S.ceval; R.g0.oms = S.omega;
+    R.g0.entry = -1; R.g0.scan0 = 1; R.g0.stride = 1; R.g0.nscan = 0; R.g0.mid0 = 0; R.g0.nmid = 0; R.g0.midslot = 0;
+    R.g0.base = S.ceval; R.g0.oms = S.omega;
     R.g1 = R.g0;
+    const int pcell = swd_teamw_predicted_cell(nx, S.pass & 1);
     if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
     if (cap <= 1) return R;
     if (S.st == SWD_ST_A) {
         // the scan is only laid out in its plain form: upwards, never turned around at clow
         // (swd_bracket_next resets c1 to clow when c1 + dc <= clow)
         R.ngrp = 1;
-        R.nt = swd_teamw_scan_layout(R.g0, 1, cap - 1, false, R.g0.base + dc > S.clow);
+        R.nt = swd_teamw_scan_layout(R.g0, 1, cap - 1, false, R.g0.base + dc > S.clow, pcell);
         return R;
     }
     if (S.st == SWD_ST_B) {
@@ -330,7 +365,8 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
         R.g0.base = S.c1;
         if (S.idir > 0 && S.c1 + dc == S.ceval && R.g0.base + dc > S.clow) {
             R.ngrp = 1;
-            R.nt = swd_teamw_scan_layout(R.g0, 0, cap, false, true);
+            // (the scan is S.nbrk cells into its search already)
+            R.nt = swd_teamw_scan_layout(R.g0, 0, cap, false, true, pcell >= S.nbrk ? pcell - S.nbrk : -1);
         }
         return R;
     }
@@ -372,18 +408,21 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
     nx.k = S.k; nx.pass = S.pass;
     R.g0.oms = R.g1.oms = nx.oms;
     const int room = cap - R.nt;
+    // the search that follows is the second solve of this period (group velocity, first solve pending) or the
+    // first solve of the next period
+    const int ncell = swd_teamw_predicted_cell(nx, (tg.igr > 0 && S.pass == 0) ? 1 : 0);
     if (depth == 0 || !per_leaf) {
         R.g0.base = ((S.pass == 0) ? S.ceval : S.ck) - onea * dc;
         R.ngrp = 1;
-        R.nt = swd_teamw_scan_layout(R.g0, R.nt, room, true, R.g0.base + dc > clows);
+        R.nt = swd_teamw_scan_layout(R.g0, R.nt, room, true, R.g0.base + dc > clows, ncell);
     } else {
         // two leaves: the midpoints of the sub-brackets (slots 1 and 2)
         const int r0 = (room + 1) / 2;
         R.g0.base = 0.5 * (S.c1 + S.ceval) - onea * dc;
         R.g1.base = 0.5 * (S.ceval + S.c2) - onea * dc;
         R.ngrp = 2;
-        R.nt = swd_teamw_scan_layout(R.g0, R.nt, r0, true, R.g0.base + dc > clows);
-        R.nt = swd_teamw_scan_layout(R.g1, R.nt, room - r0, true, R.g1.base + dc > clows);
+        R.nt = swd_teamw_scan_layout(R.g0, R.nt, r0, true, R.g0.base + dc > clows, ncell);
+        R.nt = swd_teamw_scan_layout(R.g1, R.nt, room - r0, true, R.g1.base + dc > clows, ncell);
         if (R.g1.entry < 0) R.ngrp = 1;
     }
     return R;
@@ -419,8 +458,9 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
     *om = g.oms;
     if (j == g.entry) { *c = g.base; return; }
     const int q = j - g.scan0;
-    const int i = g.stride == 2 ? q >> 1 : q;        // scan cell
-    const bool mid = g.stride == 2 && (q & 1);
+    const bool pmid = g.nmid > 0 && j >= g.midslot;  // a predicted midpoint behind the scan slots
+    const int i = pmid ? g.mid0 + (j - g.midslot) : g.stride == 2 ? q >> 1 : q;        // scan cell
+    const bool mid = pmid || (g.stride == 2 && (q & 1));
     // base_0 = base, base_{n+1} = c_n = base_n + dc by repeated addition.  The scan stops at the first
     // base outside [cc, cfail) (swd_control: "c1 < cm or c1 >= betmx + dc -> no root"); the bases
     // increase, so it is enough to look at the first and at this cell's
@@ -574,7 +614,7 @@ BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, 
 template <class Lay, class Src, class Vals, class Nev>
 BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const SwdTargetDev &tg,
                              const double *BH_RESTRICT per, int wss, const TeamwRound &R, const Vals &vals,
-                             bool tree = true)
+                             TeamwNext &nx, bool tree = true)
 {
     const double dc = (double)0.005f;
     int used = 0;
@@ -636,7 +676,10 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
                 }
             }
         }
+        const bool scanning = S.st == SWD_ST_B;
+        const int pass = S.pass & 1;
         swd_control(S, vals.del(j), nv);
+        if (scanning && S.st == SWD_ST_TOP) { nx.cellp[pass] = nx.cell[pass]; nx.cell[pass] = S.nbrk; }    // bracketed in cell nbrk of its scan
         used++;
         vals.probe(6);
         vals.count(11, 1);

@@ -108,6 +108,11 @@ extern "C" int hs_surfdisp96_team(const float *thkm, const float *vpm, const flo
     return src.err;
 }
 
+// Optional statistics of the wide-team replay: hist[st][nev][min(used, 15)] counts rounds by the state the
+// search was in when the round was planned (ST_A .. ST_MID), nevill's `nev`, and the values consumed.
+static long *g_round_hist = nullptr;
+extern "C" void hs_teamw_set_histogram(long *hist) { g_round_hist = hist; }
+
 // CPU replay of the wide-team kernel (swd_teamw_kernel): speculation across the end of a root search,
 // values consumed by (omega, c) match.  `nlanes` = 64 * W virtual lanes.
 namespace {
@@ -158,7 +163,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
     bh::swd_state_init(S);
     double nx[12], ny[12];
     bh::NevMem nv{nx, ny};
-    bh::TeamwNext nxt{-1, -1, 0.0};
+    bh::TeamwNext nxt{-1, -1, 0.0, {-1, -1}, {-1, -1}};
     bh::swd_nev_init(nv);
     long nc = 0, ns = 0, nr = 0;
     for (;;) {
@@ -183,6 +188,17 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
             }
         }
         if (R.ngrp > 1 && (R.g0.scan0 + R.g0.nscan * R.g0.stride > R.g1.entry + (R.g0.stride - 1))) return -105;
+        for (int gi = 0; gi < R.ngrp; gi++) {             // predicted midpoints: behind their scan, of its cells
+            const bh::TeamwScan &g = gi ? R.g1 : R.g0;
+            if (g.nmid == 0) continue;
+            if (g.stride != 1 || g.midslot != g.scan0 + g.nscan || g.mid0 < 0 || g.mid0 + g.nmid > g.nscan) return -106;
+            if (g.midslot + g.nmid > nt || (gi == 0 && R.ngrp > 1 && g.midslot + g.nmid > R.g1.entry)) return -107;
+            for (int m = 0; m < g.nmid; m++) {
+                const int cell = g.mid0 + m, jm = g.midslot + m, jc = g.scan0 + cell;
+                const double lo = cell == 0 ? g.base : tc[jc - 1], hi = tc[jc];
+                if (hi == hi && tc[jm] == tc[jm] && tc[jm] != 0.5 * (lo + hi)) return -108;
+            }
+        }
         for (int j = 0; j < nt; j++) {
             if (tc[j] != tc[j]) { dl[j] = 0.0; continue; }                    // NaN slot: not evaluated
             for (int rr = 0; rr < nlm; rr++)
@@ -197,10 +213,15 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         std::memcpy(qx, nx, sizeof(qx)); std::memcpy(qy, ny, sizeof(qy));
         bh::NevMem qv{qx, qy};
         const int k0 = S.k, pass0 = S.pass, iq0 = S.iq;
-        nc += bh::swd_teamw_consume(S, nv, lay, src, tg, t, 1, R, vals);
+        const int st0 = S.st, nev0 = S.nev;
+        bh::TeamwNext nxq = nxt;
+        const int used_now = bh::swd_teamw_consume(S, nv, lay, src, tg, t, 1, R, vals, nxt);
+        nc += used_now;
+        if (g_round_hist && st0 >= 0 && st0 < 4 && nev0 >= 0 && nev0 < 3)
+            g_round_hist[(st0 * 3 + nev0) * 16 + (used_now < 15 ? used_now : 15)]++;
         if (S.k == k0 && S.pass == pass0 && S.iq == iq0 && S.st != bh::SWD_ST_DONE && S.ev == bh::SWD_EV_NONE) {
             NullSrc nsrc;
-            bh::swd_teamw_consume(Sq, qv, lay, nsrc, tg, t, 1, R, vals, false);
+            bh::swd_teamw_consume(Sq, qv, lay, nsrc, tg, t, 1, R, vals, nxq, false);
             auto same = [](double a, double b) { return a == b || (a != a && b != b); };
             if (Sq.st != S.st || Sq.nev != S.nev || Sq.m != S.m || Sq.nctrl != S.nctrl || Sq.idir != S.idir ||
                 Sq.nbrk != S.nbrk || !same(Sq.c1, S.c1) || !same(Sq.c2, S.c2) || !same(Sq.c3, S.c3) ||
