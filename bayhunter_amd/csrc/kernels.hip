@@ -454,9 +454,10 @@ __device__ __forceinline__ T *uni(T *p)
     return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                  (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
-struct LdsDel {                    // period-equation values of the round's slots
-    const double *d;
-    __device__ __forceinline__ double operator()(int j) const { return d[j]; }
+struct LdsSlots {                  // period-equation values and trial velocities of the round's slots (LDS)
+    const double *d, *tc;
+    __device__ __forceinline__ double del(int j) const { return d[j]; }
+    __device__ __forceinline__ double c(int j) const { return tc[j]; }
 };
 struct TeamwVals {
     double mc, mom, dl;                   // slot (lane & 63) of the round and its value
@@ -655,7 +656,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     WideSrc src{A, tg, t, lane, nl, 0, b, res};
     SwdState S;
     swd_state_init(S);
-    TeamwNext nxt{-1, -1, 0.0, {-1, -1}, {-1, -1}};
+    TeamwNext nxt{-1, -1, 0.0};
     BH_TP_DECL;
     long rounds = 0;
     bool first = true;
@@ -667,6 +668,11 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     for (;;) {
         bool fin = false;
         int nt = 1;
+#if defined(BH_TEAMW_USTATE)
+        S.c1 = uni(S.c1); S.c2 = uni(S.c2); S.c3 = uni(S.c3); S.del1 = uni(S.del1); S.del2 = uni(S.del2); S.del3 = uni(S.del3);
+        S.clow = uni(S.clow); S.del1st = uni(S.del1st); S.ceval = uni(S.ceval); S.omega = uni(S.omega);
+        S.cprev = uni(S.cprev); S.ck = uni(S.ck); S.cc = uni(S.cc); S.cfail = uni(S.cfail);
+#endif
         if (ctl) {
             // (no event pending in all but one round per search: do not even enter the driver's loop --
             // the copies between the two loop headers were 7 % of a round)
@@ -754,7 +760,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             unsigned long long goL = 0, goR = 0;
             if (R.nhalf > 0) {
                 const bool innode = wl <= R.nhalf;
-                nd = swd_teamw_node(S, LdsDel{dels}, innode ? wl : 0);
+                nd = swd_teamw_node(S, R, LdsSlots{dels, tcl}, innode ? wl : 0);
                 goL = __ballot(innode && nd.go == SWD_GO_LEFT);
                 goR = __ballot(innode && nd.go == SWD_GO_RIGHT);
             }
@@ -764,7 +770,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
 #else
             TeamwVals v{mc, mom, wl < nt ? dels[wl] : 0.0, nt, nd, goL, goR};
 #endif
-            const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v, nxt);
+            const int used = swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
             BH_TP(4);
             BH_TP_COUNT(8, used);
             BH_TP_COUNT(9, nt);

@@ -280,65 +280,83 @@ struct TeamwScan {                // an entry evaluation (optional) and the scan
     int entry;                    // slot of the entry evaluation (c = base), or -1
     int scan0, stride, nscan;     // scan trial i in slot scan0 + i*stride, i < nscan (stride 2: cell
                                   // midpoints in between)
-    int mid0, nmid, midslot;      // stride 1: midpoints of the cells mid0 .. mid0+nmid-1 only, in slots midslot ..
     double base, oms;             // the point the scan steps away from, omega of the scan
 };
 struct TeamwRound {
     int nt;                       // slots in use
-    int nhalf;                    // bisection candidates in slots 1 .. nhalf (0, 2, 6, 14, 30 or 62): the
-                                  // tree in level order, left (c1 side) to right
+    int nhalf;                    // bisection candidates in slots 1 .. nhalf
+    int chains;                   // 0: slots 1 .. nhalf (0, 2, 6, 14, 30 or 62) are the complete tree in level
+                                  //    order, left (c1 side) to right
+                                  // 1: the two INNER CHAINS below a pending Neville estimate x (see swd_teamw_round):
+                                  //    slot 2i-1 = A_i, slot 2i = B_i, i = 1 .. nhalf/2
     int ngrp;                     // scan groups in use (0..2); g1 follows g0
     TeamwScan g0, g1;
 };
+enum { SWD_TEAMW_CHAIN_MAX = 14 };   // deepest inner chain (0.005 -> 1e-6 c takes 11-13 halvings)
 
 // omega of the search that follows the current one, kept across the rounds of a search (k, pass)
 struct TeamwNext {
     int k, pass;
     double oms;
-    // The cell of its bracketing scan in which the last root search of each pass (first solve / second solve of
-    // a group-velocity pair) found the sign change, -1 before the first one.  A dispersion curve is smooth and
-    // the periods are evenly spaced more often than not, so the next search of the same pass finds its sign
-    // change in that cell or a neighbour: their midpoints -- nevill's first point (surfdisp96.f:583), otherwise a
-    // round of its own with one trial -- ride along with a scan too short for a midpoint per cell.
-    int cell[2], cellp[2];        // the last such cell of each pass and the one before: the prediction extrapolates
 };
-// the cell in which the next search of `pass` is expected to find its sign change, or -1
-BH_DEV int swd_teamw_predicted_cell(const TeamwNext &nx, int pass)
-{
-    const int c0 = nx.cell[pass], c1 = nx.cellp[pass];
-    if (c0 < 0) return -1;
-    const int p = c1 < 0 ? c0 : 2 * c0 - c1;        // (a dispersion curve bends slowly: 70 % within one cell)
-    return p < 0 ? 0 : p;
-}
-#ifndef SWD_TEAMW_NMID
-#define SWD_TEAMW_NMID 3          // predicted cell and a neighbour on either side
-#endif
 
-// lays one scan group out in slots [first, first + room): entry (if has_entry) + scan.  want_cell: the cell
-// (counted from this scan's first one) in which the sign change is expected, or < 0.
-BH_DEV int swd_teamw_scan_layout(TeamwScan &g, int first, int room, bool has_entry, bool scan_ok, int want_cell = -1)
+// The number of halvings that bring a bracket of width w down to tol: the smallest i >= 0 with w / 2^i <= tol,
+// at most SWD_TEAMW_CHAIN_MAX (w, tol > 0 and finite; anything else: 0).  Powers of two scale exactly, so this is
+// a comparison of exponents and one of mantissas.
+BH_DEV int swd_halvings(double w, double tol)
 {
-    g.entry = -1; g.scan0 = first; g.stride = 1; g.nscan = 0; g.mid0 = 0; g.nmid = 0; g.midslot = 0;
+    if (!(w > tol) || !(tol > 0.0)) return 0;
+#if defined(BH_HOSTSIM)
+    int ew, et;
+    const double mw = std::frexp(w, &ew), mt = std::frexp(tol, &et);
+#else
+    const int ew = __builtin_amdgcn_frexp_exp(w), et = __builtin_amdgcn_frexp_exp(tol);
+    const double mw = __builtin_amdgcn_frexp_mant(w), mt = __builtin_amdgcn_frexp_mant(tol);
+#endif
+    int i = ew - et + (mw > mt ? 1 : 0);            // w = mw 2^ew, tol = mt 2^et, mantissas in [0.5, 1)
+    return i < 0 ? 0 : i > SWD_TEAMW_CHAIN_MAX ? SWD_TEAMW_CHAIN_MAX : i;
+}
+
+// lays one scan group out in slots [first, first + room): entry (if has_entry) + scan
+BH_DEV int swd_teamw_scan_layout(TeamwScan &g, int first, int room, bool has_entry, bool scan_ok)
+{
+    g.entry = -1; g.scan0 = first; g.stride = 1; g.nscan = 0;
     if (room <= 0) return first;
     if (has_entry) { g.entry = first; g.scan0 = first + 1; room--; }
     if (!scan_ok || room <= 0) return g.scan0;
-    if (room >= SWD_TEAMW_MIDROOM) {
-        g.stride = 2;
-        g.nscan = (room + 1) / 2;                   // odd room: the last cell has no midpoint
-        return g.scan0 + room;
-    }
-    g.nscan = room;
-#if SWD_TEAMW_NMID > 0
-    // a few midpoints behind the scan slots, if the predicted cell is one of those this scan reaches
-    int lo = want_cell - SWD_TEAMW_NMID / 2;
-    if (lo < 0) lo = 0;
-    const int nscan = room - SWD_TEAMW_NMID;
-    if (want_cell >= 0 && nscan >= SWD_TEAMW_NMID && want_cell < nscan) {
-        if (lo + SWD_TEAMW_NMID > nscan) lo = nscan - SWD_TEAMW_NMID;
-        g.nscan = nscan; g.mid0 = lo; g.nmid = SWD_TEAMW_NMID; g.midslot = g.scan0 + nscan;
-    }
-#endif
+    g.stride = room >= SWD_TEAMW_MIDROOM ? 2 : 1;
+    g.nscan = (room + g.stride - 1) / g.stride;     // stride 2 and odd room: the last cell has no midpoint
     return g.scan0 + room;
+}
+
+// The search that follows the current one, if it is predictable (mirror of swd_driver; only the plain case --
+// fundamental mode, no workspace): its omega into nx (kept across the rounds of a search), the lower bound of its
+// scan, and whether it starts from the root about to be found (per_leaf) or from c(k) of the first solve.
+BH_DEV bool swd_teamw_follow(const SwdState &S, const SwdTargetDev &tg, const double *BH_RESTRICT per,
+                             TeamwNext &nx, bool *per_leaf, double *clows)
+{
+    const double TWOPI = 2.0 * 3.141592653589793, one = 1.0e-2, dc = (double)0.005f;
+    const float h = 0.005f;
+    *per_leaf = true;
+    *clows = 0.0;
+    if (tg.mode != 1 || S.iq != 1 || S.ceval > (double)S.betmx) return false;
+    const bool fresh = nx.k != S.k || nx.pass != S.pass;
+    if (tg.igr > 0 && S.pass == 0) {                // second solve of the pair, surfdisp96.f:282-294
+        if (fresh) nx.oms = TWOPI / (double)S.t1b;
+        *clows = 0.0 + one * dc;
+    } else {                                        // next period, surfdisp96.f:231-239,268-271
+        const int k2 = S.k + 1;
+        if (k2 > tg.nper || k2 >= S.ift) return false;
+        if (fresh) {
+            double t1 = per[k2 - 1];
+            if (tg.igr > 0) t1 = (double)(float)(t1 / (double)(1.f + h));
+            nx.oms = TWOPI / t1;
+        }
+        *per_leaf = S.pass == 0;                    // (pass 1: it starts from c(k), the first root)
+        *clows = S.cc;
+    }
+    nx.k = S.k; nx.pass = S.pass;
+    return true;
 }
 
 BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, const double *BH_RESTRICT per,
@@ -346,18 +364,16 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
 {
     const double dc = (double)0.005f;
     TeamwRound R;
-    R.nt = 1; R.nhalf = 0; R.ngrp = 0;
-    R.g0.entry = -1; R.g0.scan0 = 1; R.g0.stride = 1; R.g0.nscan = 0; R.g0.mid0 = 0; R.g0.nmid = 0; R.g0.midslot = 0;
-    R.g0.base = S.ceval; R.g0.oms = S.omega;
+    R.nt = 1; R.nhalf = 0; R.ngrp = 0; R.chains = 0;
+    R.g0.entry = -1; R.g0.scan0 = 1; R.g0.stride = 1; R.g0.nscan = 0; R.g0.base = S.ceval; R.g0.oms = S.omega;
     R.g1 = R.g0;
-    const int pcell = swd_teamw_predicted_cell(nx, S.pass & 1);
     if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
     if (cap <= 1) return R;
     if (S.st == SWD_ST_A) {
         // the scan is only laid out in its plain form: upwards, never turned around at clow
         // (swd_bracket_next resets c1 to clow when c1 + dc <= clow)
         R.ngrp = 1;
-        R.nt = swd_teamw_scan_layout(R.g0, 1, cap - 1, false, R.g0.base + dc > S.clow, pcell);
+        R.nt = swd_teamw_scan_layout(R.g0, 1, cap - 1, false, R.g0.base + dc > S.clow);
         return R;
     }
     if (S.st == SWD_ST_B) {
@@ -365,16 +381,78 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
         R.g0.base = S.c1;
         if (S.idir > 0 && S.c1 + dc == S.ceval && R.g0.base + dc > S.clow) {
             R.ngrp = 1;
-            // (the scan is S.nbrk cells into its search already)
-            R.nt = swd_teamw_scan_layout(R.g0, 0, cap, false, true, pcell >= S.nbrk ? pcell - S.nbrk : -1);
+            R.nt = swd_teamw_scan_layout(R.g0, 0, cap, false, true);
         }
         return R;
     }
-    // refinement.  Evaluations left if every step from here on is a bisection: the pending one, plus
+    const double onea = 1.5;
+    R.chains = 0;
+    const double wa = fabs(S.ceval - S.c1), wb = fabs(S.c2 - S.ceval), tol = 1.e-6 * fabs(S.ceval);
+    bool per_leaf;                                  // the start of the search that follows depends on this root
+    double clows;
+
+    // ---- inner chains.  The pending trial x is a Neville estimate (nev == 2): it sits within ~1e-5 of the root,
+    // so whichever side of it the root is on, the bisections that follow all move the FAR end of the bracket
+    // towards x -- forced while the end values differ by > 100x (surfdisp96.f:620-640) -- until the next Neville
+    // step or the stopping test.  Of the complete tree below x only two paths are ever taken (replay: 1 968
+    // refinement rounds, 5 exceptions, all on low-velocity-zone models): L R R R ... and R L L L ....  Those two
+    // chains cost 2 slots per level instead of 2^level: with 16 slots a round follows 7 halvings instead of 3.
+    //   A_i = mid(A_{i-1}, x), A_0 = c1  (after x: c2 = x, then c1 = A_1, c1 = A_2, ...)
+    //   B_i = mid(x, B_{i-1}), B_0 = c2  (after x: c1 = x, then c2 = B_1, c2 = B_2, ...)
+    // A chain is no longer than the halvings left on its side before |c1 - c2| <= 1e-6 c1 fires (:614).
+#if !defined(BH_TEAMW_NO_CHAINS)                  // (A/B switch: the complete tree everywhere)
+    if (S.nev == 2 && cap >= 5) {
+        // nodes of chain A / B evaluated until the stopping test: the smallest i with w / 2^i <= tol
+        const int ia = swd_halvings(wa, tol), ib = swd_halvings(wb, tol);
+        int D = ia > ib ? ia : ib;
+        if (D > (cap - 1) / 2) D = (cap - 1) / 2;
+        if (D >= 2) {
+            R.chains = 1;
+            R.nhalf = 2 * D;
+            R.nt = 1 + R.nhalf;
+            // behind a chain that reaches its stopping test within the round comes the search that follows: its
+            // last node is then the root (the last estimate, not a midpoint of the final bracket)
+            const int room = cap - R.nt;
+            const bool enda = ia >= 1 && ia <= D, endb = ib >= 1 && ib <= D;
+            if (room < 2 || !(enda || endb) || !swd_teamw_follow(S, tg, per, nx, &per_leaf, &clows)) return R;
+            R.g0.oms = R.g1.oms = nx.oms;
+            if (!per_leaf) {
+                R.g0.base = S.ck - onea * dc;
+                R.ngrp = 1;
+                R.nt = swd_teamw_scan_layout(R.g0, R.nt, room, true, R.g0.base + dc > clows);
+                return R;
+            }
+            double ra = S.c1, rb = S.c2;            // the chains' last nodes (one loop for both: the steps of a
+            {                                       // chain depend on each other)
+                const int na = enda ? ia : 0, nb = endb ? ib : 0, nmax = na > nb ? na : nb;
+                for (int i = 0; i < nmax; i++) {
+                    const double ta = 0.5 * (ra + S.ceval), tb = 0.5 * (S.ceval + rb);
+                    ra = i < na ? ta : ra;
+                    rb = i < nb ? tb : rb;
+                }
+            }
+            if (enda && endb) {
+                const int r0 = (room + 1) / 2;
+                R.g0.base = ra - onea * dc;
+                R.g1.base = rb - onea * dc;
+                R.ngrp = 2;
+                R.nt = swd_teamw_scan_layout(R.g0, R.nt, r0, true, R.g0.base + dc > clows);
+                R.nt = swd_teamw_scan_layout(R.g1, R.nt, room - r0, true, R.g1.base + dc > clows);
+                if (R.g1.entry < 0) R.ngrp = 1;
+            } else if (enda || endb) {
+                R.g0.base = (enda ? ra : rb) - onea * dc;
+                R.ngrp = 1;
+                R.nt = swd_teamw_scan_layout(R.g0, R.nt, room, true, R.g0.base + dc > clows);
+            }
+            return R;
+        }
+    }
+#endif
+
+    // ---- complete tree.  Evaluations left if every step from here on is a bisection: the pending one, plus
     // one per halving until the bracket is narrower than the stopping tolerance.
     int left = 1;
     {
-        const double wa = fabs(S.ceval - S.c1), wb = fabs(S.c2 - S.ceval), tol = 1.e-6 * fabs(S.ceval);
         const double w = wa > wb ? wa : wb;
         left += (w > tol) + (w > 2.0 * tol) + (w > 4.0 * tol) + (w > 8.0 * tol) + (w > 16.0 * tol);
     }
@@ -382,47 +460,23 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
     while (depth < left - 1 && (4 << depth) - 1 <= cap) depth++;
     R.nhalf = (2 << depth) - 2;
     R.nt = 1 + R.nhalf;
-    // the search that follows, behind the leaves if they are the last evaluations of this one (mirror
-    // of swd_driver; only the plain case -- fundamental mode, no workspace -- is predicted)
-    if (depth != left - 1 || depth > 1 || R.nt >= cap || tg.mode != 1 || S.iq != 1 || S.ceval > (double)S.betmx)
+    // the search that follows, behind the leaves if they are the last evaluations of this one
+    if (depth != left - 1 || depth > 1 || R.nt >= cap || !swd_teamw_follow(S, tg, per, nx, &per_leaf, &clows))
         return R;
-    const double TWOPI = 2.0 * 3.141592653589793, one = 1.0e-2, onea = 1.5;
-    const float h = 0.005f;
-    const bool fresh = nx.k != S.k || nx.pass != S.pass;
-    double clows;
-    bool per_leaf = true;                           // the start of the next search depends on this root
-    if (tg.igr > 0 && S.pass == 0) {                // second solve of the pair, surfdisp96.f:282-294
-        if (fresh) nx.oms = TWOPI / (double)S.t1b;
-        clows = 0.0 + one * dc;
-    } else {                                        // next period, surfdisp96.f:231-239,268-271
-        const int k2 = S.k + 1;
-        if (k2 > tg.nper || k2 >= S.ift) return R;
-        if (fresh) {
-            double t1 = per[k2 - 1];
-            if (tg.igr > 0) t1 = (double)(float)(t1 / (double)(1.f + h));
-            nx.oms = TWOPI / t1;
-        }
-        per_leaf = S.pass == 0;                     // (pass 1: it starts from c(k), the first root)
-        clows = S.cc;
-    }
-    nx.k = S.k; nx.pass = S.pass;
     R.g0.oms = R.g1.oms = nx.oms;
     const int room = cap - R.nt;
-    // the search that follows is the second solve of this period (group velocity, first solve pending) or the
-    // first solve of the next period
-    const int ncell = swd_teamw_predicted_cell(nx, (tg.igr > 0 && S.pass == 0) ? 1 : 0);
     if (depth == 0 || !per_leaf) {
         R.g0.base = ((S.pass == 0) ? S.ceval : S.ck) - onea * dc;
         R.ngrp = 1;
-        R.nt = swd_teamw_scan_layout(R.g0, R.nt, room, true, R.g0.base + dc > clows, ncell);
+        R.nt = swd_teamw_scan_layout(R.g0, R.nt, room, true, R.g0.base + dc > clows);
     } else {
         // two leaves: the midpoints of the sub-brackets (slots 1 and 2)
         const int r0 = (room + 1) / 2;
         R.g0.base = 0.5 * (S.c1 + S.ceval) - onea * dc;
         R.g1.base = 0.5 * (S.ceval + S.c2) - onea * dc;
         R.ngrp = 2;
-        R.nt = swd_teamw_scan_layout(R.g0, R.nt, r0, true, R.g0.base + dc > clows, ncell);
-        R.nt = swd_teamw_scan_layout(R.g1, R.nt, room - r0, true, R.g1.base + dc > clows, ncell);
+        R.nt = swd_teamw_scan_layout(R.g0, R.nt, r0, true, R.g0.base + dc > clows);
+        R.nt = swd_teamw_scan_layout(R.g1, R.nt, room - r0, true, R.g1.base + dc > clows);
         if (R.g1.entry < 0) R.ngrp = 1;
     }
     return R;
@@ -440,6 +494,15 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
     const double dc = (double)0.005f;
     *c = S.ceval; *om = S.omega;
     if (j <= 0) return;
+    if (j <= R.nhalf && R.chains) {
+        // inner chains: A_i in slot 2i-1, B_i in slot 2i; midpoints taken exactly like nevill (:583,:661)
+        const int i = (j + 1) >> 1;
+        double a = (j & 1) ? S.c1 : S.c2;
+        if (j & 1) { for (int t = 0; t < i; t++) a = 0.5 * (a + S.ceval); }
+        else { for (int t = 0; t < i; t++) a = 0.5 * (S.ceval + a); }
+        *c = a;
+        return;
+    }
     if (j <= R.nhalf) {
         // node j of the bisection tree in level order: level l = floor(log2(j+1)), position p in the
         // level; walk down from the pending trial, a bit of p per level (0: the value there has the
@@ -458,9 +521,8 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
     *om = g.oms;
     if (j == g.entry) { *c = g.base; return; }
     const int q = j - g.scan0;
-    const bool pmid = g.nmid > 0 && j >= g.midslot;  // a predicted midpoint behind the scan slots
-    const int i = pmid ? g.mid0 + (j - g.midslot) : g.stride == 2 ? q >> 1 : q;        // scan cell
-    const bool mid = pmid || (g.stride == 2 && (q & 1));
+    const int i = g.stride == 2 ? q >> 1 : q;        // scan cell
+    const bool mid = g.stride == 2 && (q & 1);
     // base_0 = base, base_{n+1} = c_n = base_n + dc by repeated addition.  The scan stops at the first
     // base outside [cc, cfail) (swd_control: "c1 < cm or c1 >= betmx + dc -> no root"); the bases
     // increase, so it is enough to look at the first and at this cell's
@@ -483,27 +545,50 @@ struct TeamwNode {
     int go;
     double c1, d1, c2, d2;        // the bracket the search has when it arrives at the node
 };
-template <class Del>
-BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const Del &del, int j)
+// slot the search was at before it arrived at node j (> 0)
+BH_DEV int swd_teamw_parent(const TeamwRound &R, int j)
+{
+    return R.chains ? (j <= 2 ? 0 : j - 2) : (j - 1) >> 1;
+}
+// `v.del(slot)`, `v.c(slot)`: period-equation value and trial velocity of a slot
+template <class V>
+BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const TeamwRound &R, const V &v, int j)
 {
     const double pct = (double)0.01f;
-    const int l = swd_ilog2(j + 1);
-    const int pth = j + 1 - (1 << l);
     TeamwNode n;
     n.c1 = S.c1; n.d1 = S.del1; n.c2 = S.c2; n.d2 = S.del2;
     double c3 = S.ceval;
-    // values of the ancestors (level m: slot ((j + 1) >> (l - m)) - 1), fetched together: the walk
-    // below is then arithmetic only
-    double da[5];
-    for (int m = 0; m < 5; m++) da[m] = del(m < l ? ((j + 1) >> (l - m)) - 1 : 0);
-    const double d3 = del(j);
-    for (int m = 0; m < 5; m++) {
-        if (m < l) {
-            const int bit = (pth >> (l - 1 - m)) & 1;
-            if (bit) { n.c1 = c3; n.d1 = da[m]; } else { n.c2 = c3; n.d2 = da[m]; }
-            c3 = 0.5 * (n.c1 + n.c2);
+    if (R.chains) {
+        // node A_i (odd j): the search has set c2 = x and then c1 = A_1 .. A_{i-1}; B_i: the mirror image.
+        // Only the pending trial and the chain's previous node enter.
+        if (j > 0) {
+            const double dx = v.del(0);
+            const int p = j - 2;                    // the chain's previous node (slot <= 0: the bracket end itself)
+            if (j & 1) {
+                n.c2 = S.ceval; n.d2 = dx;
+                if (p > 0) { n.c1 = v.c(p); n.d1 = v.del(p); }
+            } else {
+                n.c1 = S.ceval; n.d1 = dx;
+                if (p > 0) { n.c2 = v.c(p); n.d2 = v.del(p); }
+            }
+            c3 = v.c(j);
+        }
+    } else {
+        const int l = swd_ilog2(j + 1);
+        const int pth = j + 1 - (1 << l);
+        // values of the ancestors (level m: slot ((j + 1) >> (l - m)) - 1), fetched together: the walk
+        // below is then arithmetic only
+        double da[5];
+        for (int m = 0; m < 5; m++) da[m] = v.del(m < l ? ((j + 1) >> (l - m)) - 1 : 0);
+        for (int m = 0; m < 5; m++) {
+            if (m < l) {
+                const int bit = (pth >> (l - 1 - m)) & 1;
+                if (bit) { n.c1 = c3; n.d1 = da[m]; } else { n.c2 = c3; n.d2 = da[m]; }
+                c3 = 0.5 * (n.c1 + n.c2);
+            }
         }
     }
+    const double d3 = v.del(j);
     bool stop = false;
     int nev = 1;                                    // (a node below the root is reached by a bisection)
     if (j == 0) {
@@ -614,7 +699,7 @@ BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, 
 template <class Lay, class Src, class Vals, class Nev>
 BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const SwdTargetDev &tg,
                              const double *BH_RESTRICT per, int wss, const TeamwRound &R, const Vals &vals,
-                             TeamwNext &nx, bool tree = true)
+                             bool tree = true)
 {
     const double dc = (double)0.005f;
     int used = 0;
@@ -624,19 +709,30 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
         int j = used == 0 ? 0 : vals.find(S.omega, S.ceval);
         vals.probe(4);
         if (j < 0) break;
-        if (tree && used == 0 && R.nhalf > 0 && S.nctrl < 90) {       // (refinement round: ST_TOP / ST_MID)
+        if (tree && used == 0 && R.nhalf > 0 && S.nctrl < 80) {       // (refinement round: ST_TOP / ST_MID)
             int last = 0, lev = 0;
-            while (2 * last + 2 <= R.nhalf) {                         // `last` has children in the tree
-                const int go = vals.go(S, last);
-                if (go == SWD_GO_STOP) break;
-                last = 2 * last + 1 + go;
-                lev++;
+            if (R.chains) {
+                // x, then down chain A (x went left: c2 = x) or B while the far end keeps moving towards x
+                const int g0 = vals.go(S, 0);
+                if (g0 != SWD_GO_STOP) {
+                    const int inner = g0 == SWD_GO_LEFT ? SWD_GO_RIGHT : SWD_GO_LEFT;
+                    last = g0 == SWD_GO_LEFT ? 1 : 2;
+                    lev = 1;
+                    while (last + 2 <= R.nhalf && vals.go(S, last) == inner) { last += 2; lev++; }
+                }
+            } else {
+                while (2 * last + 2 <= R.nhalf) {                     // `last` has children in the tree
+                    const int go = vals.go(S, last);
+                    if (go == SWD_GO_STOP) break;
+                    last = 2 * last + 1 + go;
+                    lev++;
+                }
             }
             if (lev > 0) {
                 const TeamwNode a = vals.node(S, last);
                 S.nctrl += lev - (S.st == SWD_ST_MID ? 1 : 0);        // (ST_MID does not count its step)
                 S.c1 = a.c1; S.del1 = a.d1; S.c2 = a.c2; S.del2 = a.d2;
-                S.del3 = vals.del((last - 1) >> 1);
+                S.del3 = vals.del(swd_teamw_parent(R, last));
                 S.c3 = vals.c(last);
                 S.ceval = S.c3;
                 S.nev = 1; S.m = 1; S.st = SWD_ST_TOP;
@@ -676,10 +772,7 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
                 }
             }
         }
-        const bool scanning = S.st == SWD_ST_B;
-        const int pass = S.pass & 1;
         swd_control(S, vals.del(j), nv);
-        if (scanning && S.st == SWD_ST_TOP) { nx.cellp[pass] = nx.cell[pass]; nx.cell[pass] = S.nbrk; }    // bracketed in cell nbrk of its scan
         used++;
         vals.probe(6);
         vals.count(11, 1);

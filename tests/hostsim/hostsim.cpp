@@ -129,12 +129,8 @@ struct ArrayVals {
     double c(int j) const { return tc[j]; }
     void probe(int) const {}
     void count(int, int) const {}
-    struct Del {
-        const double *dl;
-        double operator()(int j) const { return dl[j]; }
-    };
-    int go(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, Del{dl}, j).go; }
-    bh::TeamwNode node(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, Del{dl}, j); }
+    int go(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, *R, *this, j).go; }
+    bh::TeamwNode node(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, *R, *this, j); }
     int run(int first, int stride, int count, bool neg) const
     {
         int m = 0;
@@ -163,7 +159,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
     bh::swd_state_init(S);
     double nx[12], ny[12];
     bh::NevMem nv{nx, ny};
-    bh::TeamwNext nxt{-1, -1, 0.0, {-1, -1}, {-1, -1}};
+    bh::TeamwNext nxt{-1, -1, 0.0};
     bh::swd_nev_init(nv);
     long nc = 0, ns = 0, nr = 0;
     for (;;) {
@@ -188,17 +184,6 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
             }
         }
         if (R.ngrp > 1 && (R.g0.scan0 + R.g0.nscan * R.g0.stride > R.g1.entry + (R.g0.stride - 1))) return -105;
-        for (int gi = 0; gi < R.ngrp; gi++) {             // predicted midpoints: behind their scan, of its cells
-            const bh::TeamwScan &g = gi ? R.g1 : R.g0;
-            if (g.nmid == 0) continue;
-            if (g.stride != 1 || g.midslot != g.scan0 + g.nscan || g.mid0 < 0 || g.mid0 + g.nmid > g.nscan) return -106;
-            if (g.midslot + g.nmid > nt || (gi == 0 && R.ngrp > 1 && g.midslot + g.nmid > R.g1.entry)) return -107;
-            for (int m = 0; m < g.nmid; m++) {
-                const int cell = g.mid0 + m, jm = g.midslot + m, jc = g.scan0 + cell;
-                const double lo = cell == 0 ? g.base : tc[jc - 1], hi = tc[jc];
-                if (hi == hi && tc[jm] == tc[jm] && tc[jm] != 0.5 * (lo + hi)) return -108;
-            }
-        }
         for (int j = 0; j < nt; j++) {
             if (tc[j] != tc[j]) { dl[j] = 0.0; continue; }                    // NaN slot: not evaluated
             for (int rr = 0; rr < nlm; rr++)
@@ -214,14 +199,13 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         bh::NevMem qv{qx, qy};
         const int k0 = S.k, pass0 = S.pass, iq0 = S.iq;
         const int st0 = S.st, nev0 = S.nev;
-        bh::TeamwNext nxq = nxt;
-        const int used_now = bh::swd_teamw_consume(S, nv, lay, src, tg, t, 1, R, vals, nxt);
+        const int used_now = bh::swd_teamw_consume(S, nv, lay, src, tg, t, 1, R, vals);
         nc += used_now;
         if (g_round_hist && st0 >= 0 && st0 < 4 && nev0 >= 0 && nev0 < 3)
             g_round_hist[(st0 * 3 + nev0) * 16 + (used_now < 15 ? used_now : 15)]++;
         if (S.k == k0 && S.pass == pass0 && S.iq == iq0 && S.st != bh::SWD_ST_DONE && S.ev == bh::SWD_EV_NONE) {
             NullSrc nsrc;
-            bh::swd_teamw_consume(Sq, qv, lay, nsrc, tg, t, 1, R, vals, nxq, false);
+            bh::swd_teamw_consume(Sq, qv, lay, nsrc, tg, t, 1, R, vals, false);
             auto same = [](double a, double b) { return a == b || (a != a && b != b); };
             if (Sq.st != S.st || Sq.nev != S.nev || Sq.m != S.m || Sq.nctrl != S.nctrl || Sq.idir != S.idir ||
                 Sq.nbrk != S.nbrk || !same(Sq.c1, S.c1) || !same(Sq.c2, S.c2) || !same(Sq.c3, S.c3) ||
