@@ -316,15 +316,16 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     const long cus = resident > 0 ? resident / 8 : 256;
     struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
     static const Form forms[8] = {
-        {0,   {3.8, 5.4, 9.92, 14.2, 31.2},   {28494, 16804, 8495, 5721, 3519}},   // lane kernel
-        {8,   {2.37, 3.31, 5.9, 6.74, 11.9},  {6620, 4323, 2456, 1646, 782}},
-        {16,  {1.94, 2.45, 4.76, 5.77, 10.3}, {3991, 2869, 1533, 1191, 972}},
-        {32,  {1.51, 1.85, 2.74, 3.9, 8.86},  {2554, 1992, 1301, 880, 687}},
-        {64,  {0.59, 0.59, 0.95, 1.59, 3.66}, {3475, 3041, 1742, 1038, 841}},
-        {128, {0.49, 0.48, 0.81, 1.05, 2.12}, {2047, 1669, 1082, 795, 553}},
-        {256, {0.42, 0.42, 0.66, 0.85, 1.46}, {1280, 1119, 728, 557, 438}},
-        {512, {0.42, 0.42, 0.57, 0.7, 1.18},  {728, 653, 477, 385, 289}},
+        {0,   {3.7, 5.3, 9.91, 14.2, 31.6},   {28309, 16869, 8744, 5815, 3441}},   // lane kernel
+        {8,   {2.38, 3.3, 5.85, 6.73, 12.2},  {6660, 4352, 2464, 1649, 781}},
+        {16,  {1.89, 2.42, 4.78, 5.87, 10.1}, {3986, 2895, 1533, 1190, 974}},
+        {32,  {1.57, 1.86, 2.79, 3.92, 8.9},  {2550, 1990, 1303, 880, 688}},
+        {64,  {0.51, 0.52, 0.95, 1.66, 3.73}, {4097, 3613, 1801, 999, 836}},
+        {128, {0.44, 0.47, 0.66, 0.94, 2.21}, {2136, 1809, 1302, 896, 562}},
+        {256, {0.38, 0.4, 0.57, 0.72, 1.45},  {1370, 1219, 868, 656, 488}},
+        {512, {0.38, 0.4, 0.5, 0.61, 0.99},   {756, 694, 560, 445, 344}},
     };
+
 
     const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
     bool team = false;
