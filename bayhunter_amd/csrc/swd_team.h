@@ -292,7 +292,9 @@ struct TeamwRound {
     int ngrp;                     // scan groups in use (0..2); g1 follows g0
     TeamwScan g0, g1;
 };
-enum { SWD_TEAMW_CHAIN_MAX = 14 };   // deepest inner chain (0.005 -> 1e-6 c takes 11-13 halvings)
+#ifndef SWD_TEAMW_CHAIN_MAX
+#define SWD_TEAMW_CHAIN_MAX 14      // deepest inner chain (0.005 -> 1e-6 c takes 11-13 halvings)
+#endif
 
 // omega of the search that follows the current one, kept across the rounds of a search (k, pass)
 struct TeamwNext {
@@ -385,6 +387,12 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
         }
         return R;
     }
+    // The first bisection after a bracket (`nevill`'s opening `half`, surfdisp96.f:583): its value decides the
+    // Neville estimate that follows, nine times in ten nothing below it is ever used (replay: 329 of 359 such
+    // rounds consume the one value) -- a round of one trial, not worth a tree.
+#if !defined(BH_TEAMW_NO_LONE)
+    if (S.nev == 1 && S.nctrl == 1 && S.st == SWD_ST_TOP) return R;
+#endif
     const double onea = 1.5;
     R.chains = 0;
     const double wa = fabs(S.ceval - S.c1), wb = fabs(S.c2 - S.ceval), tol = 1.e-6 * fabs(S.ceval);
