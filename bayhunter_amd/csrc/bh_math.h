@@ -197,4 +197,15 @@ BH_DEV cd cexp_(cd z)
     return mk(e * c, e * s);
 }
 
+
+// The same without bh_exp's range clamps: the exponent of a phase factor of the receiver-function recursion
+// is w d Im(slowness) -- attenuation, or the decay of an evanescent wave: the reduction handles any magnitude
+// a layered model can produce (ldexp saturates to 0 / inf, NaN propagates through the polynomial).
+BH_DEV cd cexp_bounded(cd z)
+{
+    double s, c, e = bh_exp_bounded(z.re);
+    bh_sincos(z.im, &s, &c);
+    return mk(e * c, e * s);
+}
+
 }  // namespace bh

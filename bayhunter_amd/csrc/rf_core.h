@@ -334,8 +334,7 @@ BH_DEV cd rf_phase3_body(const double *S, const RfLayout &lo, const RfLaunch &P,
         gs = crecip(fs * fs);
     }
     for (int i = 0; i < nlay - 1; i++) {        // reference layer index i+1 = 1 .. nlay-1
-        const double d = par[i];
-        cd miwd = mk(0., -w * d);
+        const double wd = w * par[i];               // exp(-i w d * slowness): (-i wd)(a + ib) = wd b - i wd a
         if (!uniform && i > 0) {                // this layer has its own Q
             const double ap = par[4 * lo.L + i], as = par[5 * lo.L + i];
             cd fp = mk(1. + lgw * ap, ap * (0.5 * BH_PI)), fs = mk(1. + lgw * as, as * (0.5 * BH_PI));
@@ -344,7 +343,11 @@ BH_DEV cd rf_phase3_body(const double *S, const RfLayout &lo, const RfLaunch &P,
         }
         cd plc = csqrt_fast(gp * par[6 * lo.L + i] - P.p2);         // Q finite -> im != 0
         cd slc = csqrt_fast(gs * par[7 * lo.L + i] - P.p2);
-        cd e11 = cexp_(miwd * plc), e22 = cexp_(miwd * slc);
+#if defined(BH_RF_OLD_CEXP)                        // (A/B switch: the general complex product and the clamped exp)
+        cd e11 = cexp_(mk(0., -wd) * plc), e22 = cexp_(mk(0., -wd) * slc);
+#else
+        cd e11 = cexp_bounded(mk(wd * plc.im, -(wd * plc.re))), e22 = cexp_bounded(mk(wd * slc.im, -(wd * slc.re)));
+#endif
         const double *ci = coef + RF_COEF * i, *cn = coef + RF_COEF * (i + 1);
         cm2 nt;
         if (i == 0) nt = to_cm2(ld_m2(ci + 16, (const M *)nullptr));                   // nt = ru[1]
