@@ -204,11 +204,18 @@ long team_threshold()
 
 int pick_rf_M(int B, int Lmax, int nsamp)
 {
-    // as many models per workgroup as fit ~52 KiB of LDS (three 4-wave workgroups per CU = 3 waves
-    // per SIMD), at most 8: with nfreq = 2^k+1 tasks per model the partial last round costs
-    // 1/(4M+1) of the issue slots
+    // Models per workgroup.  rf_kernel is built for four waves per SIMD (128 VGPRs), so that one of its
+    // workgroups fits next to the two 192-VGPR waves per SIMD of swd_kernel (2 x 192 + 128 = 512) and the two
+    // kernels of a joint evaluation share the CUs from the start instead of running one after the other; the LDS
+    // has to allow it too: eight swd_kernel waves hold 8 x 15.7 KiB of a CU's 160 KiB (ten layers, 21 periods),
+    // which leaves ~31 KiB -- three 512-sample models.  Alone, four such workgroups per CU (98 KiB) keep all
+    // four waves per SIMD resident.  (Six models per workgroup, the round-2 choice, is 1 % faster alone -- no
+    // partial last round of tasks -- and can never be co-resident: 65.1 -> 61.2 ms per joint step, same box,
+    // profiles/r03_ab_rf_coresident.txt.)
     size_t per = bh::rf_lds_bytes(Lmax, nsamp, 1);
-    int M = (int)((52 * 1024) / per);
+    int M = (int)((26 * 1024) / per);
+    static const char *force = std::getenv("BH_RF_M");       // A/B switch (diagnostic)
+    if (force && std::atoi(force) > 0) M = std::atoi(force);
     if (M > 8) M = 8;
     if (M < 1) M = 1;
     if (M > B) M = B;

@@ -811,10 +811,14 @@ __device__ __forceinline__ void rf_block_fft(double *S, int per_model, int Mb, i
     }
 }
 
-// 3 waves per SIMD (<= 168 VGPRs, a few spilled dwords): the recursion is latency-bound at 2.
+// 4 waves per SIMD (128 VGPRs, nothing spilled): alone the recursion is latency-bound at 2 and equally fast
+// at 3 or 4; at 128 VGPRs a workgroup also fits beside swd_kernel's two waves per SIMD (capi.hip: pick_rf_M).
 // ZR: also keep the filtered vertical/radial spectra and return their traces (synrf_cwrap's fz, fr).
+#ifndef BH_RF_WAVES
+#define BH_RF_WAVES 4
+#endif
 template <bool ZR>
-__global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(3, 3))) void rf_kernel(RfArgs A)
+__global__ __launch_bounds__(RF_T) __attribute__((amdgpu_waves_per_eu(BH_RF_WAVES, BH_RF_WAVES))) void rf_kernel(RfArgs A)
 {
     extern __shared__ double S[];
     const RfLaunch &P = A.P;

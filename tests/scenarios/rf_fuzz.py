@@ -2,7 +2,8 @@
 
 Random batch size, depth (1..40 layers, uniform or ragged), low-velocity zones, Gauss factor, slowness,
 transform length (64..4096), sampling rate, P / SV, fixed or model-derived rotation velocity.  Reports the
-largest deviation relative to the trace's scale; NaN patterns must be identical.
+largest deviation relative to the trace's scale; NaN patterns must be identical; the deviation must be within
+tests/tolerances.py: rf_bound (1e-10, or 4x the oracle's own spread under one ulp of slowness where that is larger).
 
     python tests/scenarios/rf_fuzz.py [seconds] [seed]  > gpurun_out/rf_fuzz.txt
 """
@@ -17,6 +18,8 @@ sys.path.insert(0, ROOT)
 from bayhunter_amd.engine import ForwardEngine, RfSpec  # noqa: E402
 from bayhunter_amd.synthetic import draw_models  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from tolerances import rf_bound  # noqa: E402
 
 
 def main(seconds=180.0, seed=1):
@@ -55,12 +58,22 @@ def main(seconds=180.0, seed=1):
         fin = np.isfinite(want).all(axis=1)
         if fin.any():
             scale = np.maximum(1.0, np.abs(want[fin]).max(axis=1, keepdims=True))
-            d = float((np.abs(out[fin] - want[fin]) / scale).max())
+            dm = (np.abs(out[fin] - want[fin]) / scale).max(axis=1)
+            d = float(dm.max())
             if d > worst:
                 worst, where = d, tag
-            if d > 1e-10:
-                print('DEVIATION %.3e > 1e-10: %s' % (d, tag), flush=True)
-                return 1
+            if d > 2e-11:
+                # rare near-singular layer stacks amplify rounding: measure the oracle's own spread under
+                # +-1 ulp of the slowness for that model and bound the deviation by tolerances.rf_bound
+                i = int(np.flatnonzero(fin)[int(dm.argmax())])
+                one = lambda q: po.rf_batch(H[i:i + 1], VP[i:i + 1], VS[i:i + 1], RHO[i:i + 1], nl[i:i + 1], q, gauss, nsamp,
+                                            fsamp, tshift, nsv, wn, nout=nobs, nthreads=1)[0]
+                spread = max(float(np.abs(one(np.nextafter(p, s)) - want[i]).max() / scale[int(dm.argmax()), 0]) for s in (0.0, 99.0))
+                print('ILL-CONDITIONED model %d of %s: deviation %.3e, the oracle itself moves by %.3e under one ulp of '
+                      'slowness (bound %.3e)' % (i, tag, d, spread, rf_bound(spread)), flush=True)
+                if d > rf_bound(spread):
+                    print('DEVIATION %.3e > %.3e: %s' % (d, rf_bound(spread), tag), flush=True)
+                    return 1
         ncfg += 1
         nmod += B
         if ncfg % 50 == 0:

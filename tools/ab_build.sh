@@ -14,7 +14,7 @@ for v in "$@"; do
     echo "== $name: flags [$flags] env [$envs]" | tee -a "$out"
     BH_EXTRA_HIPCC_FLAGS="$flags" python -c "from bayhunter_amd import _lib; _lib.build(force=True)"
     for w in ${loads:-joint10}; do
-        env BH_EXTRA_HIPCC_FLAGS="$flags" $envs python bench.py --workload "$w" --steps 5 --warmup 2 --no-cpu-baseline --no-chain-pool \
+        env BH_EXTRA_HIPCC_FLAGS="$flags" $envs python bench.py --workload "$w" --steps 5 --warmup 2 --no-cpu-baseline --no-chain-pool --no-configs \
             | python -c "
 import sys, json
 for l in sys.stdin:
