@@ -168,6 +168,8 @@ _SIGS = {
     "bh_set_device": (C.c_int, [C.c_int]),
     "bh_swd_set_kernel": (C.c_int, [C.c_int]),
     "bh_swd_last_form": (C.c_int, []),
+    "bh_swd_last_forms": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "bh_swd_plan_forms": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SwdTarget), C.c_int, C.POINTER(C.c_int)]),
     "bh_rf_active_frequencies": (C.c_int, [C.POINTER(RfParams)]),
     "surfdisp96_": (None, [_vp] * 13),
     "synrf_cwrap": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -113,6 +113,7 @@ int get_freq_table(const bh::RfLaunch &P, double fsamp, const double **out)
 // waited for -- with more launches in flight than slots the caller blocks instead of two kernels
 // sharing (and corrupting) one counter.  BH_SWD_QUEUE_SLOTS shrinks the ring (test hook).
 constexpr int kQueueSlots = 256;
+constexpr int kAuxStreams = 2;       // + the caller's stream: at most three kernel forms per call
 struct DevState {
     unsigned int *queue = nullptr;
     unsigned long next = 0;
@@ -121,6 +122,11 @@ struct DevState {
     bool used[kQueueSlots];
     bool claimed[kQueueSlots];        // taken by a host thread that has not recorded its event yet
     unsigned long waits = 0;          // how often a launch had to wait for its slot (diagnostic)
+    // a call whose targets go to different kernel forms launches them on the caller's stream and on these
+    // (shared by all calls on the device); the fork/join events belong to the slot, like `done`
+    hipStream_t aux[kAuxStreams] = {nullptr, nullptr};
+    hipEvent_t fork[kQueueSlots], join[kQueueSlots][kAuxStreams];
+    bool forked[kQueueSlots];
 };
 std::mutex g_dev_mutex;
 std::map<int, DevState> g_dev;
@@ -136,7 +142,7 @@ int get_queue_slot(unsigned int **slot, int *slot_index, int *resident_waves)
         hipDeviceProp_t prop;
         BH_HIP(hipGetDeviceProperties(&prop, dev));
         d.cus = prop.multiProcessorCount;
-        for (int i = 0; i < kQueueSlots; i++) d.used[i] = d.claimed[i] = false;
+        for (int i = 0; i < kQueueSlots; i++) d.used[i] = d.claimed[i] = d.forked[i] = false;
         if (const char *e = std::getenv("BH_SWD_QUEUE_SLOTS")) {
             int v = std::atoi(e);
             if (v >= 1 && v <= kQueueSlots) d.nslots = v;
@@ -192,14 +198,131 @@ int release_queue_slot(int i, hipStream_t stream)
     return BH_OK;
 }
 
+// streams and events for a call that launches `naux` kernels beside the one on the caller's stream (slot `i` is
+// claimed by the calling thread)
+struct SlotStreams {
+    hipStream_t aux[kAuxStreams];
+    hipEvent_t fork, join[kAuxStreams];
+};
+int get_slot_streams(int i, int naux, SlotStreams *out)
+{
+    int dev = 0;
+    BH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    DevState &d = g_dev[dev];
+    if (naux > kAuxStreams) return fail_arg("too many concurrent kernel forms");
+    for (int k = 0; k < naux; k++)
+        if (!d.aux[k]) BH_HIP(hipStreamCreateWithFlags(&d.aux[k], hipStreamNonBlocking));
+    if (!d.forked[i]) {
+        BH_HIP(hipEventCreateWithFlags(&d.fork[i], hipEventDisableTiming));
+        for (int k = 0; k < kAuxStreams; k++) BH_HIP(hipEventCreateWithFlags(&d.join[i][k], hipEventDisableTiming));
+        d.forked[i] = true;
+    }
+    out->fork = d.fork[i];
+    for (int k = 0; k < kAuxStreams; k++) { out->aux[k] = d.aux[k]; out->join[k] = d.join[i][k]; }
+    return BH_OK;
+}
+
 // kernel choice of bh_swd_batch: process-wide default (bh_swd_set_kernel), read once per call
 std::atomic<int> g_swd_mode{BH_SWD_AUTO};
-thread_local int g_last_form = -1;    // what the last bh_swd_batch of this thread launched (bh_swd_last_form)
+thread_local int g_last_form = -1;
+thread_local int g_last_forms[bh::BH_NT] = {0};   // per target (bh_swd_last_forms)    // what the last bh_swd_batch of this thread launched (bh_swd_last_form)
 
 long team_threshold()
 {
     static const char *e = std::getenv("BH_SWD_TEAM_MAX");
     return e ? std::atol(e) : 0;       // 0: eight searches per resident wave
+}
+
+// Work of one search of a target relative to the table's unit (Rayleigh phase velocity at 21 periods): group
+// velocities solve each period twice (x1.66 period-equation evaluations, bench.py N_DLTAR), a Love layer step
+// costs 0.56 of a Rayleigh one (tools/target_forms.py), mode m runs m root searches per period.
+double target_weight(const bh_swd_target &s)
+{
+    return (s.nper / 21.0) * (s.igr ? 1.66 : 1.0) * (s.iwave == 1 ? 0.56 : 1.0) * (double)s.mode;
+}
+
+// Which kernel form runs each target of a call (width[t]: 0 = lane kernel, else lanes per search).
+// Each form k has a latency lat_k (one search, chip mostly idle) and a saturation rate thr_k (searches per ms
+// with every SIMD busy); a call with s searches costs about max(lat_k, s / thr_k).  Table measured on MI355X
+// (256 CUs) for 21 periods, Rayleigh phase (profiles/r03_team_widths.txt, fitted by tools/fit_forms.py; relative
+// order is what matters), by deepest model of the batch; thr scales with the CU count.  Wide teams (64 W lanes,
+// speculation across root searches) win up to a few thousand searches, 8-lane teams in the ten-thousands, the
+// lane kernel beyond.  bh_swd_set_kernel overrides; BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
+//
+// Several targets: first the one form that is best for all of them (as above).  One refinement, where it was
+// measured to pay: the call is latency-bound on the lane kernel -- a few thousand models, every search has a SIMD
+// to itself and the call takes as long as its heaviest target (four targets x 8192 ten-layer models, 40 periods:
+// 22.7 ms, the Rayleigh group velocities) -- and the batch fits the 8-lane teams at one wave per SIMD
+// (B <= 32 searches per CU, at most 20 layers).  The heaviest target then runs on the 8-lane teams, on a second stream beside the
+// others, if the estimate max(max_t lat w_t, sum_t B w_t / thr) drops by 10 % or more (same example: 18.7 ms).
+// Nothing else is moved: with more models the teams share SIMDs and lose more than the lane kernel gains, and
+// moves between team forms measured worse throughout (tools/auto_forms.py, profiles/r03_mixed_forms.txt).
+// BH_SWD_NO_MIXED=1 keeps one form per call (A/B).
+void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, long cus, int swd_mode, int *width)
+{
+    struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
+    static const Form forms[8] = {
+        {0,   {3.7, 5.3, 9.91, 14.2, 31.6},   {28309, 16869, 8744, 5815, 3441}},   // lane kernel
+        {8,   {2.38, 3.3, 5.85, 6.73, 12.2},  {6660, 4352, 2464, 1649, 781}},
+        {16,  {1.89, 2.42, 4.78, 5.87, 10.1}, {3986, 2895, 1533, 1190, 974}},
+        {32,  {1.57, 1.86, 2.79, 3.92, 8.9},  {2550, 1990, 1303, 880, 688}},
+        {64,  {0.51, 0.52, 0.95, 1.66, 3.73}, {4097, 3613, 1801, 999, 836}},
+        {128, {0.44, 0.47, 0.66, 0.94, 2.21}, {2136, 1809, 1302, 896, 562}},
+        {256, {0.38, 0.4, 0.57, 0.72, 1.45},  {1370, 1219, 868, 656, 488}},
+        {512, {0.38, 0.4, 0.5, 0.61, 0.99},   {756, 694, 560, 445, 344}},
+    };
+    if (swd_mode != BH_SWD_AUTO) {
+        const int w = swd_mode == BH_SWD_LANE ? 0 : swd_mode == BH_SWD_TEAM8 ? 8 : swd_mode == BH_SWD_TEAM16 ? 16
+                    : swd_mode == BH_SWD_TEAM32 ? 32 : swd_mode == BH_SWD_TEAM128 ? 128
+                    : swd_mode == BH_SWD_TEAM256 ? 256 : swd_mode == BH_SWD_TEAM512 ? 512 : 64;
+        for (int t = 0; t < ntargets; t++) width[t] = w;
+        return;
+    }
+    const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
+    const long searches = (long)B * ntargets;
+    auto allowed = [&](const Form &f) {
+        if (f.width == 0) return true;
+        if (team_threshold() > 0 && searches > team_threshold()) return false;
+        return bh::swd_team_lds_bytes(Lmax, f.width) <= 160 * 1024;
+    };
+    int uniform = 0;
+    double best = 1e300;
+    for (int k = 0; k < 8; k++) {
+        const Form &f = forms[k];
+        if (!allowed(f)) continue;
+        const double thr = f.thr[regime] * (double)cus / 256.0;
+        const double cost = std::fmax(f.lat[regime], (double)searches / thr);
+        if (cost < best) { best = cost; uniform = k; }
+    }
+    int form[bh::BH_NT];
+    for (int t = 0; t < ntargets; t++) form[t] = uniform;
+    static const bool no_mixed = std::getenv("BH_SWD_NO_MIXED") != nullptr;
+    if (ntargets > 1 && !no_mixed && uniform == 0 && regime <= 3 && (long)B <= 32 * cus && allowed(forms[1])) {
+        double w[bh::BH_NT];
+        for (int t = 0; t < ntargets; t++) w[t] = target_weight(targets[t]);
+        auto cost_of = [&](const int *fm) {
+            double lat = 0.0, sum = 0.0;
+            for (int t = 0; t < ntargets; t++) {
+                const Form &f = forms[fm[t]];
+                lat = std::fmax(lat, f.lat[regime] * w[t]);
+                sum += (double)B * w[t] / (f.thr[regime] * (double)cus / 256.0);
+            }
+            return std::fmax(lat, sum);
+        };
+        double cur = cost_of(form);
+        for (int pass = 0; pass + 1 < ntargets; pass++) {
+            int worst = -1;                                  // the lane-kernel target the call is waiting for
+            for (int t = 0; t < ntargets; t++)
+                if (form[t] == 0 && (worst < 0 || w[t] > w[worst])) worst = t;
+            if (worst < 0) break;
+            form[worst] = 1;
+            const double c = cost_of(form);
+            if (c > 0.9 * cur) { form[worst] = 0; break; }
+            cur = c;
+        }
+    }
+    for (int t = 0; t < ntargets; t++) width[t] = forms[form[t]].width;
 }
 
 int pick_rf_M(int B, int Lmax, int nsamp)
@@ -311,66 +434,82 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     int resident = 0, slot = 0;
     rc = get_queue_slot(&A.counters, &slot, &resident);
     if (rc) return rc;
-    const int swd_mode = g_swd_mode.load(std::memory_order_relaxed);
-    // Which kernel: each form k has a latency lat_k (one search, chip mostly idle) and a saturation
-    // rate thr_k (searches per ms with every SIMD busy); a call with s searches costs about
-    // max(lat_k, s / thr_k).  Table measured on MI355X (256 CUs) for 21 periods, Rayleigh phase
-    // (profiles/r03_team_widths.txt, fitted by tools/fit_forms.py; relative order is what matters), by deepest model of the batch;
-    // thr scales with the CU count.  Wide teams (64 W lanes, speculation across root searches) win up
-    // to a few thousand searches, 8-lane teams in the ten-thousands, the lane kernel beyond.
-    // bh_swd_set_kernel overrides; BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
-    const long searches = (long)B * ntargets;
     const long cus = resident > 0 ? resident / 8 : 256;
-    struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
-    static const Form forms[8] = {
-        {0,   {3.7, 5.3, 9.91, 14.2, 31.6},   {28309, 16869, 8744, 5815, 3441}},   // lane kernel
-        {8,   {2.38, 3.3, 5.85, 6.73, 12.2},  {6660, 4352, 2464, 1649, 781}},
-        {16,  {1.89, 2.42, 4.78, 5.87, 10.1}, {3986, 2895, 1533, 1190, 974}},
-        {32,  {1.57, 1.86, 2.79, 3.92, 8.9},  {2550, 1990, 1303, 880, 688}},
-        {64,  {0.51, 0.52, 0.95, 1.66, 3.73}, {4097, 3613, 1801, 999, 836}},
-        {128, {0.44, 0.47, 0.66, 0.94, 2.21}, {2136, 1809, 1302, 896, 562}},
-        {256, {0.38, 0.4, 0.57, 0.72, 1.45},  {1370, 1219, 868, 656, 488}},
-        {512, {0.38, 0.4, 0.5, 0.61, 0.99},   {756, 694, 560, 445, 344}},
-    };
-
-
-    const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
-    bool team = false;
-    int width = 64, team_resident = resident;
-    double best = 1e300;
-    for (int k = 0; k < 8; k++) {
-        const Form &f = forms[k];
-        if (f.width > 0) {
-            if (team_threshold() > 0 && searches > team_threshold()) continue;
-            if (bh::swd_team_lds_bytes(Lmax, f.width) > 160 * 1024) continue;
+    int width[bh::BH_NT];
+    plan_forms(B, Lmax, ntargets, targets, cus, g_swd_mode.load(std::memory_order_relaxed), width);
+    // one launch per kernel form; the form with the heaviest target goes first, on the caller's stream
+    struct Launch { int width, n; double weight; unsigned char sel[bh::BH_NT]; };
+    Launch launches[bh::BH_NT];
+    int nlaunch = 0;
+    for (int t = 0; t < ntargets; t++) {
+        int k = 0;
+        while (k < nlaunch && launches[k].width != width[t]) k++;
+        if (k == nlaunch) { launches[k].width = width[t]; launches[k].n = 0; launches[k].weight = 0.0; nlaunch++; }
+        launches[k].sel[launches[k].n++] = (unsigned char)t;
+        launches[k].weight = std::fmax(launches[k].weight, target_weight(targets[t]));
+        g_last_forms[t] = width[t];
+    }
+    for (int a = 1; a < nlaunch; a++)
+        if (launches[a].weight > launches[0].weight) std::swap(launches[a], launches[0]);
+    hipStream_t main_stream = (hipStream_t)stream;
+    hipError_t le = hipMemsetAsync(A.counters, 0, bh::BH_NT * sizeof(unsigned int), main_stream);
+    SlotStreams ss;
+    if (le == hipSuccess && nlaunch > 1) {
+        rc = get_slot_streams(slot, nlaunch - 1, &ss);
+        if (rc) { release_queue_slot(slot, main_stream); return rc; }
+        le = hipEventRecord(ss.fork, main_stream);            // the models (and the zeroed counters) are ready
+    }
+    for (int a = 0; a < nlaunch && le == hipSuccess; a++) {
+        const Launch &l = launches[a];
+        hipStream_t st = a == 0 ? main_stream : ss.aux[a - 1];
+        if (a > 0) le = hipStreamWaitEvent(st, ss.fork, 0);
+        if (le != hipSuccess) break;
+        A.nsel = l.n;
+        std::memcpy(A.tsel, l.sel, sizeof(A.tsel));
+        if (l.width > 0) {
+            int w = l.width;
+            while (w > 64 && bh::swd_team_lds_bytes(Lmax, w) > 160 * 1024) w /= 2;
+            int team_resident = resident;
+            if (w < 64) {           // persistent waves of a narrow-team kernel that stay resident
+                long per_cu = (long)(160 * 1024 / bh::swd_team_lds_bytes(Lmax, w));
+                long waves = cus * (per_cu > 8 ? 8 : per_cu);
+                team_resident = (int)(waves > 0 ? waves : 1);
+            }
+            le = bh::launch_swd_team(A, w, team_resident, st);
+        } else {
+            le = bh::launch_swd(A, resident, st);
         }
-        const double thr = f.thr[regime] * (double)cus / 256.0;
-        const double cost = std::fmax(f.lat[regime], (double)searches / thr);
-        if (cost < best) { best = cost; team = f.width > 0; width = f.width > 0 ? f.width : 64; }
+        if (a > 0 && le == hipSuccess) le = hipEventRecord(ss.join[a - 1], st);
     }
-    auto narrow_resident = [&](int w) {       // persistent waves of a narrow-team kernel that stay resident
-        long per_cu = (long)(160 * 1024 / bh::swd_team_lds_bytes(Lmax, w));
-        long waves = cus * (per_cu > 8 ? 8 : per_cu);
-        return (int)(waves > 0 ? waves : 1);
-    };
-    if (swd_mode == BH_SWD_LANE) team = false;
-    else if (swd_mode >= BH_SWD_TEAM) {
-        team = true;
-        width = swd_mode == BH_SWD_TEAM8 ? 8 : swd_mode == BH_SWD_TEAM16 ? 16 : swd_mode == BH_SWD_TEAM32 ? 32
-              : swd_mode == BH_SWD_TEAM128 ? 128 : swd_mode == BH_SWD_TEAM256 ? 256
-              : swd_mode == BH_SWD_TEAM512 ? 512 : 64;
+    // the caller's stream continues when every launch is done -- also after a failed launch, for those that
+    // were started
+    // (an event that was not recorded in this call is complete: waiting for it costs nothing)
+    for (int a = 1; a < nlaunch; a++) {
+        hipError_t we = hipStreamWaitEvent(main_stream, ss.join[a - 1], 0);
+        if (le == hipSuccess) le = we;
     }
-    while (team && width > 64 && bh::swd_team_lds_bytes(Lmax, width) > 160 * 1024) width /= 2;
-    if (team && width < 64) team_resident = narrow_resident(width);
-    hipError_t le = team ? bh::launch_swd_team(A, width, team_resident, (hipStream_t)stream)
-                         : bh::launch_swd(A, resident, (hipStream_t)stream);
-    g_last_form = team ? width : 0;
-    rc = release_queue_slot(slot, (hipStream_t)stream);    // also after a failed launch: the slot is free
+    g_last_form = launches[0].width;
+    rc = release_queue_slot(slot, main_stream);    // also after a failed launch: the slot is free
     if (le != hipSuccess) return fail_hip(le, "dispersion kernel launch");
     return rc;
 }
 
 int bh_swd_last_form(void) { return g_last_form; }
+
+int bh_swd_plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, int cus, int *forms)
+{
+    if (B < 1 || Lmax < 1 || Lmax > BH_MAX_LAYERS || ntargets < 1 || ntargets > BH_MAX_TARGETS || !targets || !forms)
+        return fail_arg("bh_swd_plan_forms: bad argument");
+    plan_forms(B, Lmax, ntargets, targets, cus > 0 ? cus : 256, g_swd_mode.load(std::memory_order_relaxed), forms);
+    return BH_OK;
+}
+
+int bh_swd_last_forms(int *forms, int ntargets)
+{
+    if (!forms || ntargets < 0 || ntargets > BH_MAX_TARGETS) return fail_arg("bh_swd_last_forms: bad argument");
+    for (int t = 0; t < ntargets; t++) forms[t] = g_last_forms[t];
+    return BH_OK;
+}
 
 int bh_swd_order_keys(int B, int Lmax, int model_stride, const int *nlay, const double *h, const double *vs,
                       double longest_period, int by_length, int *keys, void *stream)

@@ -26,8 +26,13 @@ struct SwdArgs {
     double *out;
     int *err;
     double *ws;
-    unsigned int *counters;  // [BH_NT] work-queue heads, zeroed by launch_swd
+    unsigned int *counters;  // [BH_NT] work-queue heads (one per target), zeroed by the caller of launch_swd*
     SwdTargetDev tg[BH_NT];
+    // A launch covers the targets tsel[0 .. nsel): blockIdx.y counts through them.  bh_swd_batch may give the
+    // targets of one call to different kernel forms (capi.hip: plan_forms), one launch per form on concurrent
+    // streams; everything a target owns (counters[t], err column t, workspace block t) keeps its index t.
+    int nsel;
+    unsigned char tsel[BH_NT];
 };
 
 struct RfArgs {

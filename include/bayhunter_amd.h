@@ -112,6 +112,14 @@ int bh_swd_set_kernel(int mode);
 /* The kernel form the last bh_swd_batch / bh_swd_batch_ordered of the calling thread launched: 0 = the
  * lane kernel, otherwise the lanes per search of the team kernel (8 .. 512); -1 before the first call. */
 int bh_swd_last_form(void);
+/* With several targets BH_SWD_AUTO may give the targets of one call to different forms (the heaviest targets
+ * of a latency-bound call to a faster form, launched beside the others on a second stream; the caller's stream
+ * continues when all of them are done): forms[t] = the form target t ran on in the calling thread's last call;
+ * bh_swd_last_form is then the form of the heaviest target. */
+int bh_swd_last_forms(int *forms, int ntargets);
+/* The same choice without a launch (host only, no device needed): forms[t] for a call with B models of at
+ * most Lmax layers on a device with `cus` compute units (<= 0: 256). */
+int bh_swd_plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, int cus, int *forms);
 int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                  const double *vp, const double *vs, const double *rho, int ntargets,
                  const bh_swd_target *targets,

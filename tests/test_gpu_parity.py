@@ -549,6 +549,39 @@ def test_rf_ill_conditioned_model_is_bounded_by_the_oracles_own_spread(lib):
     assert int(err.sum()) == 0 and d <= rf_bound(spread) and spread > 1e-11, (d, spread)
 
 
+@pytest.mark.parametrize('case', ['cfg3', 'modes'])
+def test_targets_of_one_call_on_different_kernel_forms(lib, case):
+    """A latency-bound call with several targets (BASELINE cfg3: 8192 models, Rayleigh + Love, phase + group, 40
+    periods) gives its heaviest target to a faster kernel form on a second stream (capi.hip: plan_forms).  The
+    values must not depend on that: same rows, bit for bit, as with every target on the lane kernel -- also for a
+    target with higher modes (its workspace block and err column keep their index)."""
+    import ctypes as C
+    from bayhunter_amd import _lib
+    from bayhunter_amd.engine import ForwardEngine, SwdSpec
+    per = np.linspace(1, 41, 40)
+    if case == 'cfg3':
+        specs = [SwdSpec(r, per) for r in ('rdispph', 'rdispgr', 'ldispph', 'ldispgr')]
+    else:
+        specs = [SwdSpec('rdispph', per[::2]), SwdSpec('rdispgr', per, mode=2), SwdSpec('ldispph', per[::2])]
+    H, VP, VS, RHO, nl = draw_models(8192, 10, seed=3100, sorted_vs=(case == 'cfg3'))
+    eng = ForwardEngine(swd=specs)
+    models = eng.upload(H, VP, VS, RHO, nl)
+    out, err = eng.run(models)
+    forms = (C.c_int * len(specs))()
+    _lib.check(lib.bh_swd_last_forms(forms, len(specs)))
+    assert len(set(forms)) > 1 and forms[1] != 0, list(forms)          # the group velocities left the lane kernel
+    out, err = out.cpu().numpy(), err.cpu().numpy()
+    _lib.set_swd_kernel('lane')
+    try:
+        want, werr = eng.run(models)
+        _lib.check(lib.bh_swd_last_forms(forms, len(specs)))
+        assert set(forms) == {0}
+    finally:
+        _lib.set_swd_kernel('auto')
+    assert np.array_equal(out, want.cpu().numpy(), equal_nan=True) and np.array_equal(err, werr.cpu().numpy())
+    assert np.count_nonzero(out) > 0.5 * out.size          # (the first higher mode does not exist at every period)
+
+
 def test_ragged_batch_is_reordered_transparently(lib, oracle):
     """Above 8192 models the searches are processed deepest first and by S travel time within a
     depth (a permutation handed to bh_swd_batch_ordered); results land in the caller's rows,

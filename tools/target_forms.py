@@ -1,0 +1,39 @@
+"""GPU-box diagnostic: ms per call of chosen kernel forms, per dispersion target and for all targets together.
+
+    python tools/target_forms.py LAYERS PERIODS MODELS ref[,ref...] form [form ...]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from bayhunter_amd import _lib  # noqa: E402
+from bayhunter_amd.engine import ForwardEngine, SwdSpec  # noqa: E402
+from bayhunter_amd.synthetic import draw_models  # noqa: E402
+
+L, P, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+refs = sys.argv[4].split(',')
+H, VP, VS, RHO, nl = draw_models(B, L, seed=3000, sorted_vs=True)
+for group in [[r] for r in refs] + ([refs] if len(refs) > 1 else []):
+    eng = ForwardEngine(swd=[SwdSpec(r, np.linspace(1, 41, P)) for r in group])
+    d = eng.upload(H, VP, VS, RHO, nl)
+    out, err = eng.alloc_out(B)
+    res = []
+    for form in sys.argv[5:]:
+        _lib.set_swd_kernel(form)
+        for _ in range(2):
+            eng.run(d, out=out, err=err)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(5):
+                eng.run(d, out=out, err=err)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 5 * 1e3)
+        res.append('%s %.2f' % (form, min(ts)))
+    _lib.set_swd_kernel('auto')
+    print('L=%d P=%d B=%d %s: ms per call ' % (L, P, B, '+'.join(group)) + '  '.join(res), flush=True)
