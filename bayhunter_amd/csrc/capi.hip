@@ -465,7 +465,8 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
         if (a > 0) le = hipStreamWaitEvent(st, ss.fork, 0);
         if (le != hipSuccess) break;
         A.nsel = l.n;
-        std::memcpy(A.tsel, l.sel, sizeof(A.tsel));
+        A.tmask = 0;
+        for (int k = 0; k < l.n; k++) A.tmask |= 1u << l.sel[k];
         if (l.width > 0) {
             int w = l.width;
             while (w > 64 && bh::swd_team_lds_bytes(Lmax, w) > 160 * 1024) w /= 2;

@@ -28,7 +28,7 @@ namespace {
         if (e_ != hipSuccess) return bh::fail_hip_((int)e_, #call);          \
     } while (0)
 
-constexpr int kOrderMin = 8192;   // below this one wave (or more) works on one search: order is irrelevant
+constexpr int kOrderMin = 1024;   // up to this every team is resident at once: order is irrelevant (layout.py: ORDER_MIN)
 
 struct Interp {                   // numpy.interp(obsx, periods, solved values) for a target with > 60 periods
     int src_off, n_src, dst_off, n_dst;

@@ -28,11 +28,13 @@ struct SwdArgs {
     double *ws;
     unsigned int *counters;  // [BH_NT] work-queue heads (one per target), zeroed by the caller of launch_swd*
     SwdTargetDev tg[BH_NT];
-    // A launch covers the targets tsel[0 .. nsel): blockIdx.y counts through them.  bh_swd_batch may give the
-    // targets of one call to different kernel forms (capi.hip: plan_forms), one launch per form on concurrent
-    // streams; everything a target owns (counters[t], err column t, workspace block t) keeps its index t.
+    // A launch covers the targets whose bit is set in tmask (nsel of them): the grid always spans all targets
+    // in y and the workgroups of the others leave at once.  bh_swd_batch may give the targets of one call to
+    // different kernel forms (capi.hip: plan_forms), one launch per form on concurrent streams.  (A list of
+    // target indices looked up by blockIdx.y cost swd_kernel six VGPRs -- 195, allocated as 200 -- and with
+    // them the co-residency with rf_kernel: 2 x 192 + 128 is all a SIMD has.)
+    unsigned int tmask;
     int nsel;
-    unsigned char tsel[BH_NT];
 };
 
 struct RfArgs {

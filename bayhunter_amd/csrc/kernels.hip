@@ -219,7 +219,8 @@ extern "C" int bh_debug_lane_profile(unsigned long long *out, int reset)
 __global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(BH_SWD_WAVES, BH_SWD_WAVES))) void swd_kernel(SwdArgs A)
 {
     extern __shared__ float lds[];
-    const int t = A.tsel[blockIdx.y];
+    const int t = blockIdx.y;
+    if (!((A.tmask >> t) & 1u)) return;              // not a target of this launch (kernels.h)
     const SwdTargetDev tg = A.tg[t];
     LdsLay lay{lds + threadIdx.x, A.Lmax};
     QueueSrc src{A, tg, A.counters + t, t, 0, A.stage ? lds + 4 * A.Lmax * SWD_T + threadIdx.x : nullptr};
@@ -362,7 +363,8 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
     constexpr int NSUB = SWD_T / TEAM;
     static_assert(NSUB > 1, "64 lanes and more per search: swd_teamw_body");
     const int sub = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
-    const int t = A.tsel[blockIdx.y];
+    const int t = blockIdx.y;
+    if (!((A.tmask >> t) & 1u)) return;              // not a target of this launch (kernels.h)
     const SwdTargetDev tg = A.tg[t];
     const int nm = A.Lmax > TEAM ? A.Lmax : TEAM;
     // per team: mats[nm][19], trials[16], dels[16] (doubles), then 4*Lmax floats (padded to doubles)
@@ -625,7 +627,8 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     constexpr int NL = SWD_T * W;
     const int lane = threadIdx.x, wl = lane & 63, wave = uni(lane >> 6);
     const bool ctl = W == 1 || wave == 0;
-    const int t = A.tsel[blockIdx.y];
+    const int t = blockIdx.y;
+    if (!((A.tmask >> t) & 1u)) return;              // not a target of this launch (kernels.h)
     const SwdTargetDev tg = A.tg[t];
     const int nm = A.Lmax > NL ? A.Lmax : NL;
     double *mats = tlds, *dels = mats + (long)nm * SWD_MAT, *perl = dels + SWD_TEAMW_NT, *nevt = perl + BH_NP;
@@ -965,7 +968,7 @@ hipError_t launch_swd_team(const SwdArgs &A, int team, int resident_waves, hipSt
     hipError_t e = ensure_dyn_lds((const void *)kern, lds, lds_set[team_index(team)]);
     if (e != hipSuccess) return e;
     if (team >= SWD_T) {           // one workgroup per search; the hardware back-fills them
-        hipLaunchKernelGGL(kern, dim3(A.B, A.nsel), dim3(team), lds, stream, A);
+        hipLaunchKernelGGL(kern, dim3(A.B, A.ntargets), dim3(team), lds, stream, A);
         return hipGetLastError();
     }
     const int nsub = SWD_T / team;
@@ -974,7 +977,7 @@ hipError_t launch_swd_team(const SwdArgs &A, int team, int resident_waves, hipSt
     int per_target = resident_waves / A.nsel;
     if (per_target < 1) per_target = 1;
     if (gx > per_target) gx = per_target;
-    hipLaunchKernelGGL(kern, dim3(gx, A.nsel), dim3(SWD_T), lds, stream, A);
+    hipLaunchKernelGGL(kern, dim3(gx, A.ntargets), dim3(SWD_T), lds, stream, A);
     return hipGetLastError();
 }
 
@@ -984,7 +987,8 @@ hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
     // (the register-limited residency) still fit 160 KiB with it
     size_t lds = (size_t)4 * A.Lmax * SWD_T * sizeof(float);
     int maxper = 0;
-    for (int k = 0; k < A.nsel; k++) maxper = A.tg[A.tsel[k]].nper > maxper ? A.tg[A.tsel[k]].nper : maxper;
+    for (int t = 0; t < A.ntargets; t++)
+        if ((A.tmask >> t) & 1u) maxper = A.tg[t].nper > maxper ? A.tg[t].nper : maxper;
     const size_t perbytes = (size_t)BH_NP * sizeof(double);                      // the target's periods
     const size_t staged = lds + (size_t)maxper * SWD_T * sizeof(float);
     SwdArgs B = A;
@@ -1005,7 +1009,7 @@ hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream)
     if (per_target < 1) per_target = 1;
     int gx = (A.B + SWD_T - 1) / SWD_T;
     if (gx > 3 * per_target) gx = per_target;
-    hipLaunchKernelGGL(swd_kernel, dim3(gx, A.nsel), dim3(SWD_T), lds, stream, B);
+    hipLaunchKernelGGL(swd_kernel, dim3(gx, A.ntargets), dim3(SWD_T), lds, stream, B);
     return hipGetLastError();
 }
 

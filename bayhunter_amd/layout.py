@@ -7,7 +7,12 @@ import numpy as np
 
 from . import _lib
 
-ORDER_MIN = 8192         # below this one wave works on one search (64/32-lane teams): order is irrelevant
+# Batches above this many models get a processing order (deepest first, ...: engine.reorder).  It is not only
+# the lane kernel that needs it: the team kernels take one search per workgroup in launch order, a thousand or
+# two are resident at a time, and a deep model started late is a tail of its own -- 8 192 ragged 2-31-layer
+# models 14.3 -> 9.8 ms, 2 048 models of 2-21 layers 2.9 -> 1.9 ms with the order (profiles/r03_order_small.txt).
+# Up to 1 024 searches every team is resident at once and the order is irrelevant.
+ORDER_MIN = 1024
 
 SWD_REFS = {'rdispgr': (2, 1), 'ldispgr': (1, 1), 'rdispph': (2, 0), 'ldispph': (1, 0)}
 RF_REFS = {'prf': 0, 'seis': 0, 'srf': 1}

@@ -354,6 +354,10 @@ def run_workload(name, B, rank, ranks, steps, warmup, serial=False, budget_s=Non
     torch.cuda.synchronize()
     dt = ranks.max(time.perf_counter() - t0)
     form = bhlib.load().bh_swd_last_form()
+    import ctypes
+    fl = (ctypes.c_int * len(swd_specs))()
+    bhlib.check(bhlib.load().bh_swd_last_forms(fl, len(swd_specs)))
+    forms = {r: int(f) for r, f in zip(wl['refs'], fl)}      # per target: a call may use one form per target
 
     # per-kernel durations for the roofline: the same launches, serialised on one stream, bracketed
     # by events on that stream (in the timed steps above rf_kernel overlaps the tail of swd_kernel)
@@ -375,10 +379,12 @@ def run_workload(name, B, rank, ranks, steps, warmup, serial=False, budget_s=Non
     ms_rf = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if eng_only_rf else 0.0
     nact = int(bhlib.load().bh_rf_active_frequencies(eng._rfp[0])) if eng_only_rf else 0
     return dict(name=name, B=B, steps=steps, dt=dt, dt_local=dt_local, ms_swd=ms_swd, ms_rf=ms_rf,
-                nerr=int(err.sum().item()), form=form, nact=nact)
+                nerr=int(err.sum().item()), form=form, forms=forms, nact=nact)
 
 
-def form_name(form):
+def form_name(form, forms=None):
+    if forms and len(set(forms.values())) > 1:         # targets of one call on different forms (capi.hip: plan_forms)
+        return 'swd kernels per target: ' + ', '.join('%s %s' % (r, 'lane' if f == 0 else 'team%d' % f) for r, f in forms.items())
     return 'swd_kernel (one search per lane)' if form == 0 else 'swd_team kernel, %d lanes per search' % form
 
 
@@ -587,7 +593,7 @@ def main():
             "roofline": dom,
             "roofline_rf": rf,
             "kernels_ms": {"swd_kernel": head['ms_swd'], "rf_kernel": head['ms_rf'],
-                           "note": "serialised; in the timed steps rf_kernel runs on a second stream and back-fills the tail of swd_kernel"},
+                           "note": "serialised; in the timed steps rf_kernel runs on a second stream, co-resident with swd_kernel (2 x 192 + 128 VGPRs per SIMD)"},
             "cpu_baseline": cpu.get(args.workload),
         }
         if cfg_runs:
@@ -598,7 +604,7 @@ def main():
                     "workload": workload_label(r['name'], r['B']),
                     "value": world * r['B'] * r['steps'] / r['dt'], "unit": "evals/s",
                     "ms_per_step": r['dt'] / r['steps'] * 1e3, "steps": r['steps'],
-                    "kernel": form_name(r['form']), "kernels_ms": {"swd": r['ms_swd'], "rf": r['ms_rf']},
+                    "kernel": form_name(r['form'], r['forms']), "kernels_ms": {"swd": r['ms_swd'], "rf": r['ms_rf']},
                     "roofline_frac": d['frac'],
                     "roofline": {k: d[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'kernel_ms')},
                     "hbm_frac": d['hbm']['frac'], "err_models": r['nerr'],

@@ -103,4 +103,4 @@ def test_single_gpu_line_has_both_rooflines_and_the_configs():
     assert sorted(d['configs']) == ['cfg2', 'cfg3', 'cfg4', 'cfg5']
     for c in d['configs'].values():
         assert c['value'] > 0 and c['ms_per_step'] > 0 and 0 < c['roofline_frac'] < 1 and c['err_models'] == 0
-        assert c['kernel'].startswith('swd_')
+        assert c['kernel'].startswith('swd')

@@ -1,0 +1,30 @@
+"""Register budgets the design depends on, checked on the cross-compiled kernels (no GPU).
+
+A joint step is 61 ms instead of 65 because one rf_kernel workgroup is resident beside swd_kernel's two waves
+per SIMD: 2 x 192 + 128 VGPRs is all a SIMD has.  Six more registers in swd_kernel -- it
+happened once, through an innocent-looking kernel argument -- and the two kernels run one after the other again
+without any test failing."""
+import os
+import sys
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+def _alloc(n):
+    return -(-n // 8) * 8          # VGPRs are allocated in blocks of 8
+
+
+def test_swd_and_rf_kernels_fit_one_simd_together():
+    from kernel_resources import kernel_resources
+    r = kernel_resources()
+    assert set(r) >= {'swd_kernel', 'rf_kernel<false>', 'rf_kernel<true>', 'swd_team_kernel', 'swd_team8_kernel',
+                      'swd_team512_kernel'}, sorted(r)
+    assert all(v['scratch'] == 0 for v in r.values()), r          # nothing spills to memory
+    assert _alloc(r['swd_kernel']['vgpr']) <= 192 and _alloc(r['rf_kernel<false>']['vgpr']) <= 128, r
+    assert 2 * _alloc(r['swd_kernel']['vgpr']) + _alloc(r['rf_kernel<false>']['vgpr']) <= 512
+    # the team forms keep two (narrow teams) / three (wide teams) waves per SIMD
+    for k, v in r.items():
+        if k.startswith('swd_team'):
+            assert _alloc(v['vgpr']) <= (256 if k in ('swd_team8_kernel', 'swd_team16_kernel', 'swd_team32_kernel') else 168), (k, v)
