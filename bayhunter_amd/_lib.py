@@ -169,6 +169,7 @@ _SIGS = {
     "bh_swd_set_kernel": (C.c_int, [C.c_int]),
     "bh_swd_last_form": (C.c_int, []),
     "bh_swd_last_forms": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "bh_swd_set_forms": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "bh_swd_plan_forms": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SwdTarget), C.c_int, C.POINTER(C.c_int)]),
     "bh_rf_active_frequencies": (C.c_int, [C.POINTER(RfParams)]),
     "surfdisp96_": (None, [_vp] * 13),
@@ -232,6 +233,17 @@ def set_swd_kernel(mode):
     (include/bayhunter_amd.h, bh_swd_set_kernel)."""
     check(load().bh_swd_set_kernel({'auto': 0, 'lane': 1, 'team': 2, 'team32': 3, 'team16': 4, 'team8': 5,
                                     'team128': 6, 'team256': 7, 'team512': 8}[mode]))
+
+
+def set_swd_forms(forms=None):
+    """Kernel form per target for this thread's next calls with len(forms) targets ('lane', 'team8', ... or
+    lanes per search); None: the library chooses again (bh_swd_set_forms)."""
+    if not forms:
+        check(load().bh_swd_set_forms(None, 0))
+        return
+    names = {'lane': 0, 'team': 64, 'team8': 8, 'team16': 16, 'team32': 32, 'team128': 128, 'team256': 256, 'team512': 512}
+    arr = (C.c_int * len(forms))(*[names.get(f, f) for f in forms])
+    check(load().bh_swd_set_forms(arr, len(forms)))
 
 
 def device_count():

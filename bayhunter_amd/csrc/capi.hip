@@ -226,7 +226,9 @@ int get_slot_streams(int i, int naux, SlotStreams *out)
 // kernel choice of bh_swd_batch: process-wide default (bh_swd_set_kernel), read once per call
 std::atomic<int> g_swd_mode{BH_SWD_AUTO};
 thread_local int g_last_form = -1;
-thread_local int g_last_forms[bh::BH_NT] = {0};   // per target (bh_swd_last_forms)    // what the last bh_swd_batch of this thread launched (bh_swd_last_form)
+thread_local int g_last_forms[bh::BH_NT] = {0};   // per target (bh_swd_last_forms)
+thread_local int g_forced_forms[bh::BH_NT] = {0};
+thread_local int g_nforced = 0;                    // > 0: bh_swd_set_forms is in force for calls with that many targets    // what the last bh_swd_batch of this thread launched (bh_swd_last_form)
 
 long team_threshold()
 {
@@ -272,6 +274,10 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
         {256, {0.38, 0.4, 0.57, 0.72, 1.45},  {1370, 1219, 868, 656, 488}},
         {512, {0.38, 0.4, 0.5, 0.61, 0.99},   {756, 694, 560, 445, 344}},
     };
+    if (g_nforced == ntargets) {                       // bh_swd_set_forms (tests, experiments)
+        for (int t = 0; t < ntargets; t++) width[t] = g_forced_forms[t];
+        return;
+    }
     if (swd_mode != BH_SWD_AUTO) {
         const int w = swd_mode == BH_SWD_LANE ? 0 : swd_mode == BH_SWD_TEAM8 ? 8 : swd_mode == BH_SWD_TEAM16 ? 16
                     : swd_mode == BH_SWD_TEAM32 ? 32 : swd_mode == BH_SWD_TEAM128 ? 128
@@ -502,6 +508,25 @@ int bh_swd_plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *target
     if (B < 1 || Lmax < 1 || Lmax > BH_MAX_LAYERS || ntargets < 1 || ntargets > BH_MAX_TARGETS || !targets || !forms)
         return fail_arg("bh_swd_plan_forms: bad argument");
     plan_forms(B, Lmax, ntargets, targets, cus > 0 ? cus : 256, g_swd_mode.load(std::memory_order_relaxed), forms);
+    return BH_OK;
+}
+
+int bh_swd_set_forms(const int *forms, int ntargets)
+{
+    if (ntargets == 0 || !forms) { g_nforced = 0; return BH_OK; }
+    if (ntargets < 0 || ntargets > BH_MAX_TARGETS) return fail_arg("bh_swd_set_forms: ntargets out of range");
+    int distinct = 0;
+    for (int t = 0; t < ntargets; t++) {
+        const int w = forms[t];
+        if (w != 0 && w != 8 && w != 16 && w != 32 && w != 64 && w != 128 && w != 256 && w != 512)
+            return fail_arg("bh_swd_set_forms: a form is 0 (lane kernel) or 8, 16, ..., 512 lanes per search");
+        bool seen = false;
+        for (int u = 0; u < t; u++) seen = seen || forms[u] == w;
+        distinct += seen ? 0 : 1;
+    }
+    if (distinct > kAuxStreams + 1) return fail_arg("bh_swd_set_forms: at most three different forms per call");
+    for (int t = 0; t < ntargets; t++) g_forced_forms[t] = forms[t];
+    g_nforced = ntargets;
     return BH_OK;
 }
 

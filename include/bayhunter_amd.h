@@ -117,6 +117,10 @@ int bh_swd_last_form(void);
  * continues when all of them are done): forms[t] = the form target t ran on in the calling thread's last call;
  * bh_swd_last_form is then the form of the heaviest target. */
 int bh_swd_last_forms(int *forms, int ntargets);
+/* Tests and experiments: the calling thread's next calls with exactly `ntargets` targets run target t on
+ * forms[t] (at most three different forms; wide forms that do not fit the LDS fall back to narrower ones as
+ * with bh_swd_set_kernel).  ntargets = 0 or forms = NULL: back to the library's choice. */
+int bh_swd_set_forms(const int *forms, int ntargets);
 /* The same choice without a launch (host only, no device needed): forms[t] for a call with B models of at
  * most Lmax layers on a device with `cus` compute units (<= 0: 256). */
 int bh_swd_plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, int cus, int *forms);

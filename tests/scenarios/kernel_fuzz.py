@@ -60,7 +60,7 @@ def main(seconds=300.0, seed=1):
     rs = np.random.RandomState(seed)
     threads = min(len(os.sched_getaffinity(0)), 16)
     t_end = time.time() + seconds
-    ncfg = nsearch = 0
+    ncfg = nsearch = nmixed = 0
     worst = dict(phase=0.0, group=0.0)
     worst_plain = dict(phase=0.0, group=0.0)          # fundamental mode, flat earth only
     where = dict(phase='', group='')
@@ -79,8 +79,18 @@ def main(seconds=300.0, seed=1):
                 res[form] = (out.cpu().numpy(), err.cpu().numpy())
             finally:
                 _lib.set_swd_kernel('auto')
+        if len(refs) > 1:        # the targets of one call on two or three different forms, concurrent streams
+            pick = list(rs.choice(('lane',) + FORMS, size=int(rs.randint(2, 4)), replace=False))
+            assign = [pick[i % len(pick)] for i in rs.permutation(len(refs))]
+            _lib.set_swd_forms(assign)
+            try:
+                out, err = eng.run(H, VP, VS, RHO, nl)
+                res['mixed'] = (out.cpu().numpy(), err.cpu().numpy())
+            finally:
+                _lib.set_swd_forms(None)
+            nmixed += 1
         tag = cfg['tag']
-        for form in FORMS:
+        for form in FORMS + (('mixed',) if 'mixed' in res else ()):
             if not (np.array_equal(res['lane'][0], res[form][0], equal_nan=True) and
                     np.array_equal(res['lane'][1], res[form][1])):
                 bad = np.argwhere(res['lane'][0] != res[form][0])
@@ -144,6 +154,8 @@ def main(seconds=300.0, seed=1):
     print('DONE: %d configurations, %d searches x %d forms, all forms bit-identical to the throughput kernel; '
           'worst relative deviation from the oracle: phase %.2e, group %.2e' % (ncfg, nsearch, len(FORMS) + 1,
                                                                                  worst['phase'], worst['group']))
+    print('   %d multi-target configurations also with their targets on two or three different forms in one call '
+          '(bh_swd_set_forms; launches on concurrent streams): bit-identical' % nmixed)
     print('   fundamental mode, flat earth only: phase %.2e, group %.2e' % (worst_plain['phase'], worst_plain['group']))
     print('   non-monotone / higher-mode / spherical values asserted against the derived bounds (phase 2.2e-6; group '
           'max(2.5e-4, 4.2e-4 |U/c|)): %d phase, %d group; largest deviation / bound: %.2f, %.2f'

@@ -582,6 +582,37 @@ def test_targets_of_one_call_on_different_kernel_forms(lib, case):
     assert np.count_nonzero(out) > 0.5 * out.size          # (the first higher mode does not exist at every period)
 
 
+def test_forced_forms_per_target_small_batches(lib):
+    """bh_swd_set_forms: three forms in one call (three concurrent launches), ragged models, more targets than
+    forms, a multimode target -- the rows of the lane kernel, bit for bit; bad arguments refused."""
+    import ctypes as C
+    from bayhunter_amd import _lib
+    from bayhunter_amd.engine import ForwardEngine, SwdSpec
+    per = np.linspace(2, 30, 9)
+    specs = [SwdSpec('rdispph', per), SwdSpec('ldispgr', per), SwdSpec('rdispgr', per, mode=2), SwdSpec('ldispph', per, flsph=1)]
+    eng = ForwardEngine(swd=specs)
+    for B, L, seed in ((1, 4, 1), (77, (2, 13), 2), (1500, 7, 3)):
+        H, VP, VS, RHO, nl = draw_models(B, L, seed=3200 + seed, sorted_vs=False)
+        _lib.set_swd_kernel('lane')
+        try:
+            want, werr = [x.cpu().numpy() for x in eng.run(H, VP, VS, RHO, nl)]
+        finally:
+            _lib.set_swd_kernel('auto')
+        for assign in (['team8', 'lane', 'team', 'lane'], ['team512', 'team512', 'team16', 'team32'], ['lane', 'team128', 'lane', 'lane']):
+            _lib.set_swd_forms(assign)
+            try:
+                out, err = [x.cpu().numpy() for x in eng.run(H, VP, VS, RHO, nl)]
+                forms = (C.c_int * 4)()
+                _lib.check(lib.bh_swd_last_forms(forms, 4))
+            finally:
+                _lib.set_swd_forms(None)
+            names = {0: 'lane', 64: 'team'}
+            assert [names.get(f, 'team%d' % f) for f in forms] == assign
+            assert np.array_equal(out, want, equal_nan=True) and np.array_equal(err, werr), (B, assign)
+    bad = (C.c_int * 4)(0, 8, 16, 32)                                   # four different forms
+    assert lib.bh_swd_set_forms(bad, 4) != 0 and lib.bh_swd_set_forms((C.c_int * 1)(7), 1) != 0
+
+
 def test_ragged_batch_is_reordered_transparently(lib, oracle):
     """Above 8192 models the searches are processed deepest first and by S travel time within a
     depth (a permutation handed to bh_swd_batch_ordered); results land in the caller's rows,

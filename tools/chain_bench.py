@@ -26,6 +26,10 @@ def main():
     case = CASES['tutorial']
     for n in sizes:
         iters = int(os.environ.get('CHAIN_BENCH_ITERS', 120 if n <= 4096 else 60))
+        # a short pool of the same size first: first-use costs (kernel forms loaded on their first launch, helper
+        # threads, pinned buffers) are not chain iterations
+        ChainPool(joint_target(data), initparams=dict(case['initparams'], iter_burnin=6, iter_main=2, acceptance=(40, 100)),
+                  modelpriors=case['priors'], seeds=np.arange(n) % 1000, nmodels=9).run()
         joint = joint_target(data)
         ip = dict(case['initparams'], iter_burnin=iters, iter_main=iters // 2, acceptance=(40, 100))
         pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=np.arange(n) % 1000,
