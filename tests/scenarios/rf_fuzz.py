@@ -3,7 +3,7 @@
 Random batch size, depth (1..40 layers, uniform or ragged), low-velocity zones, Gauss factor, slowness,
 transform length (64..4096), sampling rate, P / SV, fixed or model-derived rotation velocity.  Reports the
 largest deviation relative to the trace's scale; NaN patterns must be identical; the deviation must be within
-tests/tolerances.py: rf_bound (1e-10, or 4x the oracle's own spread under one ulp of slowness where that is larger).
+tests/tolerances.py: rf_bound (1e-10, or 16x the oracle's own spread under one ulp of slowness where that is larger).
 
     python tests/scenarios/rf_fuzz.py [seconds] [seed]  > gpurun_out/rf_fuzz.txt
 """

@@ -75,9 +75,14 @@ TOL_RF = 1.0e-10                # receiver function, absolute at amplitudes <= ~
 
 def rf_bound(spread):
     """Bound on |rf - oracle| / scale for a model whose own conditioning is known: `spread` is how far
-    the ORACLE's trace moves when the slowness is changed by +-1 ulp.  One model in ~1e6 of the random
-    campaign (tests/rf_extreme.py: ill_conditioned_model) amplifies rounding 4e4 times -- a near-singular
-    layer stack -- and the oracle differs from itself by 6.6e-11 there; any other evaluation order, the
-    replay with glibc math included (1.2e-10), lands equally far away.  Everywhere else TOL_RF holds."""
-    return max(TOL_RF, 4.0 * spread)
+    the ORACLE's trace moves when the slowness is changed by +-1 ulp.  About one model in 5e5 of the random
+    campaign (tests/rf_extreme.py: ill_conditioned_model is the worst) amplifies rounding 1e3 - 4e4 times -- a
+    near-singular layer stack -- and the oracle differs from itself by up to 6.6e-11 there; any other evaluation
+    order, the replay with glibc math included (1.2e-10), lands equally far away.  One ulp of one input is a
+    probe of the conditioning, not the sum of the few dozen roundings on the path: deviation / spread was
+    1.2, 2.5, 5.6 and 9.8 at the four models beyond 2e-11 in 1.8e6 (profiles/r03_rf_fuzz.txt), hence 16.
+    Everywhere else TOL_RF holds."""
+    return max(TOL_RF, 16.0 * spread)
+
+
 TOL_MISFIT = 1.0e-6             # north_star: RMS misfit on the tutorial dataset
