@@ -511,19 +511,29 @@ struct TeamwVals {
     }
 };
 
-// Rayleigh chain of trial (qc, qom) on the calling lane's quad; matrices of its layers at m0.
+// Rayleigh chain of trial (qc, qom) on the calling lane's quad; matrices of its layers in slots slot0 .. of mats.
 // Operation for operation swd_dunkin_apply (ee = e * ca in the reference's order, normc; the
 // max-abs of normc skips NaN entries exactly like v_max_f64 does).
 struct QuadCols {                 // column i (this lane's component) and column 4 of one layer matrix
     double a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
 };
-__device__ __forceinline__ void quad_load(QuadCols &q, const double *p, int i)
+// Column i of the 5x5 out of the 19 stored values (swd_team.h: SWD_MAT): rows 1-3 of columns 0..3 sit at
+// i, 5 + i, 9 + i; rows 4 and 5 at k4, k5 (a lane's constants for the whole chain); column 4 is c15 c14 c35 c12 c11.
+struct QuadIdx {
+    int i, k4, k5;
+};
+__device__ __forceinline__ QuadIdx quad_idx(int i)
 {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    const d2_t a01 = *(const d2_t *)(p + 6 * i), a23 = *(const d2_t *)(p + 6 * i + 2);
-    const d2_t b01 = *(const d2_t *)(p + 24), b23 = *(const d2_t *)(p + 26);
-    q.a0 = a01.x; q.a1 = a01.y; q.a2 = a23.x; q.a3 = a23.y; q.a4 = p[6 * i + 4];
-    q.b0 = b01.x; q.b1 = b01.y; q.b2 = b23.x; q.b3 = b23.y; q.b4 = p[28];
+    QuadIdx x;
+    x.i = i;
+    x.k4 = i == 3 ? 6 : 14 + i;                       // c41 c42 c43 c22
+    x.k5 = i == 0 ? 17 : i == 1 ? 14 : i == 2 ? 18 : 5;   // c51 c41 c53 c21
+    return x;
+}
+__device__ __forceinline__ void quad_load(QuadCols &q, const double *p, const QuadIdx &x)
+{
+    q.a0 = p[x.i]; q.a1 = p[5 + x.i]; q.a2 = p[9 + x.i]; q.a3 = p[x.k4]; q.a4 = p[x.k5];
+    q.b0 = p[4]; q.b1 = p[3]; q.b2 = p[13]; q.b3 = p[1]; q.b4 = p[0];
 }
 __device__ __forceinline__ void quad_apply(double e[5], const QuadCols &q)
 {
@@ -552,9 +562,9 @@ struct OneLay {
 };
 template <class Lay>
 __device__ __forceinline__ double swd_teamw_chain_quad(const Lay &lay, const OneLay &half, const SwdState &S,
-                                                       double qc, double qom, const double *m0)
+                                                       double qc, double qom, const double *mats, int slot0)
 {
-    const int i = threadIdx.x & 3;
+    const QuadIdx x = quad_idx(threadIdx.x & 3);
     const int nlm = S.mmax - S.llw;
     const double wvno = qom / qc;
     double omega = qom;
@@ -562,16 +572,14 @@ __device__ __forceinline__ double swd_teamw_chain_quad(const Lay &lay, const One
     double e[5];
     swd_ray_halfspace(half, S.mmax, wvno, wvno * wvno, omega, e);
     // two layers per trip, their columns loaded one layer ahead into alternating register sets
-    const double *p = m0 + (long)(nlm - 1) * SWD_MAT;
     QuadCols qa, qb;
     int r = nlm;
-    if (r > 0) quad_load(qa, p, i);
+    if (r > 0) quad_load(qa, mats + swd_mat_off(slot0 + r - 1), x);
     while (r >= 2) {
-        quad_load(qb, p - SWD_MAT, i);
+        quad_load(qb, mats + swd_mat_off(slot0 + r - 2), x);
         quad_apply(e, qa);
-        if (r > 2) quad_load(qa, p - 2 * SWD_MAT, i);
+        if (r > 2) quad_load(qa, mats + swd_mat_off(slot0 + r - 3), x);
         quad_apply(e, qb);
-        p -= 2 * SWD_MAT;
         r -= 2;
     }
     if (r == 1) quad_apply(e, qa);
@@ -631,7 +639,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     if (!((A.tmask >> t) & 1u)) return;              // not a target of this launch (kernels.h)
     const SwdTargetDev tg = A.tg[t];
     const int nm = A.Lmax > NL ? A.Lmax : NL;
-    double *mats = tlds, *dels = mats + (long)nm * SWD_MAT, *perl = dels + SWD_TEAMW_NT, *nevt = perl + BH_NP;
+    double *mats = tlds, *dels = mats + swd_mat_off(nm), *perl = dels + SWD_TEAMW_NT, *nevt = perl + BH_NP;
     double *tcl = nevt + 24 * W, *toml = tcl + SWD_TEAMW_NT;
     float *res = (float *)(toml + SWD_TEAMW_NT);                 // [BH_NP] staged results
     int *hdr = (int *)(nevt + 24);                               // W > 1: {command, nt, mmax, llw} of the round
@@ -730,12 +738,12 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             if (ja < nt && nlm > 0) {
                 const double ac = tcl[ja];
                 if (ac == ac)                                           // (NaN: a scan slot out of bounds)
-                    swd_teamw_assemble_one(mine, tg.iwave, S, ra, ac, toml[ja], mats + (long)lane * SWD_MAT);
+                    swd_teamw_assemble_one(mine, tg.iwave, S, ra, ac, toml[ja], mats + swd_mat_off(lane));
             }
         } else {
             const double c0 = tcl[0], om0 = toml[0];
             for (int r = lane; r < nlm; r += NL)
-                swd_teamw_assemble_one(lay, tg.iwave, S, r, c0, om0, mats + (long)r * SWD_MAT);
+                swd_teamw_assemble_one(lay, tg.iwave, S, r, c0, om0, mats + swd_mat_off(r));
         }
         const bool qvalid = jq < nt;
         const double qc = tcl[qvalid ? jq : 0], qom = toml[qvalid ? jq : 0];
@@ -747,11 +755,11 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             // through the chain (on trial 0, as an invalid quad does) took issue slots from the wave that
             // shares its SIMD: 8 700 instead of 5 700 cycles per round on 15 layers (team512).
             if (W == 1 || 16 * wave < nt) {
-                const double del = swd_teamw_chain_quad(lay, half, S, qc, qom, mats + (long)(qvalid ? jq : 0) * nlm * SWD_MAT);
+                const double del = swd_teamw_chain_quad(lay, half, S, qc, qom, mats, (qvalid ? jq : 0) * nlm);
                 if (qvalid && (wl & 3) == 0) dels[jq] = del;
             }
         } else if (lane < nt) {
-            dels[lane] = swd_teamw_chain_one(lay, 1, S, mc, mom, mats + (long)lane * nlm * SWD_MAT);
+            dels[lane] = swd_teamw_chain_one(lay, 1, S, mc, mom, mats, lane * nlm);
         }
         __syncthreads();
         BH_TP(3);
@@ -785,10 +793,13 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     (void)rounds;
 }
 
-__global__ __launch_bounds__(SWD_T) void swd_team_kernel(SwdArgs A) { swd_teamw_body<1>(A); }
-__global__ __launch_bounds__(2 * SWD_T) void swd_team128_kernel(SwdArgs A) { swd_teamw_body<2>(A); }
-__global__ __launch_bounds__(4 * SWD_T) void swd_team256_kernel(SwdArgs A) { swd_teamw_body<4>(A); }
-__global__ __launch_bounds__(8 * SWD_T) void swd_team512_kernel(SwdArgs A) { swd_teamw_body<8>(A); }
+// Three waves per SIMD: <= 168 VGPRs (the body needs ~140; without the bound the register allocator spreads out
+// to 189 and, with the 12.9 KB of LDS a 64-lane team takes, the registers would be what limits a CU to eight teams).
+#define BH_TEAMW_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+__global__ __launch_bounds__(SWD_T) BH_TEAMW_ATTR void swd_team_kernel(SwdArgs A) { swd_teamw_body<1>(A); }
+__global__ __launch_bounds__(2 * SWD_T) BH_TEAMW_ATTR void swd_team128_kernel(SwdArgs A) { swd_teamw_body<2>(A); }
+__global__ __launch_bounds__(4 * SWD_T) BH_TEAMW_ATTR void swd_team256_kernel(SwdArgs A) { swd_teamw_body<4>(A); }
+__global__ __launch_bounds__(8 * SWD_T) BH_TEAMW_ATTR void swd_team512_kernel(SwdArgs A) { swd_teamw_body<8>(A); }
 
 // -------------------------------------------------------------------------------------------- RF
 // bit reversal (+ 1/sqrt(n)) and radix-2 butterflies of Mb buffers in LDS; all threads of the group
@@ -943,9 +954,9 @@ extern "C" int bh_debug_team_profile(unsigned long long *out, int reset)
 // LDS of one workgroup of the team kernels with `team` lanes per search
 size_t swd_team_lds_bytes(int Lmax, int team)
 {
-    if (team >= SWD_T) {           // wide teams: mats[max(Lmax, lanes)][SWD_MAT], dels, periods, layer stack
+    if (team >= SWD_T) {           // wide teams: max(Lmax, lanes) matrix slots, dels, periods, layer stack
         const int nm = Lmax > team ? Lmax : team;
-        return ((size_t)nm * SWD_MAT + 3 * SWD_TEAMW_NT + BH_NP + 24 * (team / SWD_T) + BH_NP / 2 + (4 * Lmax + 1) / 2) * sizeof(double);
+        return ((size_t)swd_mat_off(nm) + 3 * SWD_TEAMW_NT + BH_NP + 24 * (team / SWD_T) + BH_NP / 2 + (4 * Lmax + 1) / 2) * sizeof(double);
     }
     const int nsub = SWD_T / team;
     const int nm = Lmax > team ? Lmax : team;

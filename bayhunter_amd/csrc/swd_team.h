@@ -208,15 +208,26 @@ BH_DEV int swd_team_consume(SwdState &S, Nev &nv, int nt, const double *trials, 
 //     swd_driver) asks for next, bit for bit, and stops at the first mismatch.  The prediction can be
 //     wrong (reversed scan direction, no convergence yet, no root) -- it can never change a result.
 //   * the Dunkin chain of a trial runs on a QUAD of lanes (component i on lane i, the fifth on all
-//     four) with DPP quad permutes instead of LDS shuffles, matrices stored column-major so that a
-//     lane's column is one 48-byte run (kernels.hip).
+//     four) with DPP quad permutes instead of LDS shuffles; a lane picks its column out of the 19 stored
+//     values of a layer matrix (kernels.hip: quad_load).
 // Trials of a round are numbered 0..nt-1; trial j has its own (c, omega).
 enum { SWD_TEAMW_NT = 64 };       // max trials per round (one per lane of the control wave)
 #ifndef SWD_TEAMW_MIDROOM
 #define SWD_TEAMW_MIDROOM 24   // scan slots from which on the cell midpoints ride along (replay: 16 and 24 within 1 %)
 #endif
 
-enum { SWD_MAT = 30 };            // doubles per stored layer matrix: 5 columns x 6 (5 used, 16-byte aligned)
+// A stored layer matrix is the 19 distinct values of Dunkin's 5x5 (+1 for Love's four: cosq, y, z, xmu), row by
+// row: 0 c11 1 c12 2 c13 3 c14 4 c15 | 5 c21 6 c22 7 c23 8 c24 | 9 c31 10 c32 11 c33 12 c34 13 c35 |
+// 14 c41 15 c42 16 c43 | 17 c51 18 c53   (c25 = c14, c44 = c22, c45 = c12, c52 = c41, c54 = c21, c55 = c11).
+// Until round 3 it was the 25 entries column by column on 30 doubles (one aligned run per lane of the quad
+// chain): 18.3 KB of LDS per 64-lane team -- eight teams per CU, two waves per SIMD where the registers allow
+// three.  With 20 doubles a team takes 12.9 KB: twelve per CU.
+enum { SWD_MAT = 20 };
+// Slot s of the store begins at double swd_mat_off(s).  (The lanes of a wave write one matrix each, 8 bytes per
+// store: with a stride of 20 doubles lanes l and l + 8 share their banks and a store takes 8 cycles instead of 2,
+// ~100 cycles per round.  One double of padding per eight slots removes that -- and the irregular stride took the
+// kernels from 142 to 189 VGPRs, i.e. from three waves per SIMD back to two: not worth it.)
+BH_HD int swd_mat_off(int s) { return s * SWD_MAT; }
 
 // floor(log2(x)) for x >= 1
 BH_DEV int swd_ilog2(int x) { return 31 - __builtin_clz((unsigned)x); }
@@ -618,19 +629,19 @@ BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const TeamwRound &R, const V 
 // Stores a Rayleigh layer matrix column by column (column i at p + 6 i: ca(1..5, i)).
 BH_DEV void swd_teamw_store_dunkin(double *p, const Dunkin &a)
 {
-    p[0] = a.c11; p[1] = a.c21; p[2] = a.c31; p[3] = a.c41; p[4] = a.c51;
-    p[6] = a.c12; p[7] = a.c22; p[8] = a.c32; p[9] = a.c42; p[10] = a.c41;
-    p[12] = a.c13; p[13] = a.c23; p[14] = a.c33; p[15] = a.c43; p[16] = a.c53;
-    p[18] = a.c14; p[19] = a.c24; p[20] = a.c34; p[21] = a.c22; p[22] = a.c21;
-    p[24] = a.c15; p[25] = a.c14; p[26] = a.c35; p[27] = a.c12; p[28] = a.c11;
+    p[0] = a.c11; p[1] = a.c12; p[2] = a.c13; p[3] = a.c14; p[4] = a.c15;
+    p[5] = a.c21; p[6] = a.c22; p[7] = a.c23; p[8] = a.c24;
+    p[9] = a.c31; p[10] = a.c32; p[11] = a.c33; p[12] = a.c34; p[13] = a.c35;
+    p[14] = a.c41; p[15] = a.c42; p[16] = a.c43;
+    p[17] = a.c51; p[18] = a.c53;
 }
 BH_DEV void swd_teamw_load_dunkin(const double *p, Dunkin &a)
 {
-    a.c11 = p[0]; a.c21 = p[1]; a.c31 = p[2]; a.c41 = p[3]; a.c51 = p[4];
-    a.c12 = p[6]; a.c22 = p[7]; a.c32 = p[8]; a.c42 = p[9];
-    a.c13 = p[12]; a.c23 = p[13]; a.c33 = p[14]; a.c43 = p[15]; a.c53 = p[16];
-    a.c14 = p[18]; a.c24 = p[19]; a.c34 = p[20];
-    a.c15 = p[24]; a.c35 = p[26];
+    a.c11 = p[0]; a.c12 = p[1]; a.c13 = p[2]; a.c14 = p[3]; a.c15 = p[4];
+    a.c21 = p[5]; a.c22 = p[6]; a.c23 = p[7]; a.c24 = p[8];
+    a.c31 = p[9]; a.c32 = p[10]; a.c33 = p[11]; a.c34 = p[12]; a.c35 = p[13];
+    a.c41 = p[14]; a.c42 = p[15]; a.c43 = p[16];
+    a.c51 = p[17]; a.c53 = p[18];
 }
 
 // Layer matrix of layer r (0-based above llw) for the trial (c, omega) into slot `p`.
@@ -653,11 +664,11 @@ BH_DEV void swd_teamw_assemble_one(const Lay &lay, int ifunc, const SwdState &S,
     }
 }
 
-// Period-equation value of the trial (c, omega) from its nlm assembled layer matrices at `m0`
-// (generic form: one lane per trial; the device runs Rayleigh trials on quads, kernels.hip).
+// Period-equation value of the trial (c, omega) from its nlm assembled layer matrices, slots slot0 .. of the
+// store `mats` (generic form: one lane per trial; the device runs Rayleigh trials on quads, kernels.hip).
 template <class Lay>
 BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, double c, double om,
-                                  const double *m0)
+                                  const double *mats, int slot0)
 {
     const int nlm = S.mmax - S.llw;
     const double wvno = om / c;
@@ -665,7 +676,7 @@ BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, 
         double e1, e2;
         swd_love_halfspace(lay, S.mmax, wvno, om, e1, e2);
         for (int r = nlm - 1; r >= 0; r--) {
-            const double *p = m0 + (long)r * SWD_MAT;
+            const double *p = mats + swd_mat_off(slot0 + r);
             LoveLayer o;
             o.cosq = p[0]; o.y = p[1]; o.z = p[2]; o.xmu = p[3];
             swd_love_apply(e1, e2, o);
@@ -678,7 +689,7 @@ BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, 
     swd_ray_halfspace(lay, S.mmax, wvno, wvno * wvno, omega, e);
     for (int r = nlm - 1; r >= 0; r--) {
         Dunkin a;
-        swd_teamw_load_dunkin(m0 + (long)r * SWD_MAT, a);
+        swd_teamw_load_dunkin(mats + swd_mat_off(slot0 + r), a);
         swd_dunkin_apply(e, a);
     }
     return (S.llw != 1) ? swd_ray_water(lay, wvno, omega, e) : e[0];

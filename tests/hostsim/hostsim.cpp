@@ -154,7 +154,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
     std::vector<double> cws(kmax > 0 ? kmax : 1), cbws(kmax > 0 ? kmax : 1);
     OneTask src{HostLay{d.data(), a.data(), b.data(), r.data()}, nlayer, 0, -1, cg, cws.data(), cbws.data()};
     const int NT = bh::SWD_TEAMW_NT;
-    std::vector<double> mats((size_t)(nlanes > nlayer ? nlanes : nlayer) * bh::SWD_MAT), tc(NT), tom(NT), dl(NT);
+    std::vector<double> mats((size_t)bh::swd_mat_off(nlanes > nlayer ? nlanes : nlayer)), tc(NT), tom(NT), dl(NT);
     bh::SwdState S;
     bh::swd_state_init(S);
     double nx[12], ny[12];
@@ -187,8 +187,8 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         for (int j = 0; j < nt; j++) {
             if (tc[j] != tc[j]) { dl[j] = 0.0; continue; }                    // NaN slot: not evaluated
             for (int rr = 0; rr < nlm; rr++)
-                bh::swd_teamw_assemble_one(lay, iwave, S, rr, tc[j], tom[j], mats.data() + ((size_t)j * nlm + rr) * bh::SWD_MAT);
-            dl[j] = bh::swd_teamw_chain_one(lay, iwave, S, tc[j], tom[j], mats.data() + (size_t)j * nlm * bh::SWD_MAT);
+                bh::swd_teamw_assemble_one(lay, iwave, S, rr, tc[j], tom[j], mats.data() + bh::swd_mat_off(j * nlm + rr));
+            dl[j] = bh::swd_teamw_chain_one(lay, iwave, S, tc[j], tom[j], mats.data(), j * nlm);
         }
         ArrayVals vals{tc.data(), tom.data(), dl.data(), &R};
         // the tree walk must leave the state one swd_control call per node leaves (checked as long as no
