@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbayhunter_amd.so")
 SOURCES = ["kernels.hip", "like_kernel.hip", "capi.hip", "evalplan.hip", "chains.cpp"]
-HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "swd_team.h", "rf_core.h", "rf_host.h", "kernels.h"]
+HEADERS = ["bh_common.h", "bh_math.h", "swd_core.h", "swd_team.h", "rf_core.h", "rf_host.h", "kernels.h",
+           "swd_form_table.h"]
 # -disable-machine-licm (device code only): the kernels are register-bound, and constants hoisted out
 # of the persistent loops (polynomial coefficients, masks) end up in VGPR pairs or spilled SGPRs and are
 # copied back at every use; rematerialised next to their use they are scalar moves.  swd_kernel 254 ->

@@ -13,6 +13,7 @@
 #include <vector>
 #include "../../include/bayhunter_amd.h"
 #include "kernels.h"
+#include "swd_form_table.h"
 #include "rf_host.h"
 
 namespace {
@@ -245,35 +246,15 @@ double target_weight(const bh_swd_target &s)
 }
 
 // Which kernel form runs each target of a call (width[t]: 0 = lane kernel, else lanes per search).
-// Each form k has a latency lat_k (one search, chip mostly idle) and a saturation rate thr_k (searches per ms
-// with every SIMD busy); a call with s searches costs about max(lat_k, s / thr_k).  Table measured on MI355X
-// (256 CUs) for 21 periods, Rayleigh phase (profiles/r03_team_widths.txt, fitted by tools/fit_forms.py; relative
-// order is what matters), by deepest model of the batch; thr scales with the CU count.  Wide teams (64 W lanes,
-// speculation across root searches) win up to a few thousand searches, 8-lane teams in the ten-thousands, the
-// lane kernel beyond.  bh_swd_set_kernel overrides; BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
+// swd_form_table.h holds the measured milliseconds per call of every form by depth regime and number of
+// searches (tools/team_sweep.py on MI355X, 256 CUs, one Rayleigh phase target at 21 periods;
+// profiles/r03_team_widths.txt); the planner interpolates in log(searches), scaled to the CU count, and takes
+// the fastest.  Wide teams (64 W lanes, speculation across root searches) win up to a few thousand searches,
+// the 64-lane teams up to ~20 000, the lane kernel beyond.  bh_swd_set_kernel / bh_swd_set_forms override;
+// BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
 //
-// Several targets: first the one form that is best for all of them (as above).  One refinement, where it was
-// measured to pay: the call is latency-bound on the lane kernel -- a few thousand models, every search has a SIMD
-// to itself and the call takes as long as its heaviest target (four targets x 8192 ten-layer models, 40 periods:
-// 22.7 ms, the Rayleigh group velocities) -- and the batch fits the 8-lane teams at one wave per SIMD
-// (B <= 32 searches per CU, at most 20 layers).  The heaviest target then runs on the 8-lane teams, on a second stream beside the
-// others, if the estimate max(max_t lat w_t, sum_t B w_t / thr) drops by 10 % or more (same example: 18.7 ms).
-// Nothing else is moved: with more models the teams share SIMDs and lose more than the lane kernel gains, and
-// moves between team forms measured worse throughout (tools/auto_forms.py, profiles/r03_mixed_forms.txt).
-// BH_SWD_NO_MIXED=1 keeps one form per call (A/B).
 void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, long cus, int swd_mode, int *width)
 {
-    struct Form { int width; double lat[5], thr[5]; };        // regimes: Lmax <= 3, <= 6, <= 12, <= 20, deeper
-    static const Form forms[8] = {
-        {0,   {3.7, 5.3, 9.91, 14.2, 31.6},   {28309, 16869, 8744, 5815, 3441}},   // lane kernel
-        {8,   {2.38, 3.3, 5.85, 6.73, 12.2},  {6660, 4352, 2464, 1649, 781}},
-        {16,  {1.89, 2.42, 4.78, 5.87, 10.1}, {3986, 2895, 1533, 1190, 974}},
-        {32,  {1.57, 1.86, 2.79, 3.92, 8.9},  {2550, 1990, 1303, 880, 688}},
-        {64,  {0.51, 0.52, 0.95, 1.66, 3.73}, {4097, 3613, 1801, 999, 836}},
-        {128, {0.44, 0.47, 0.66, 0.94, 2.21}, {2136, 1809, 1302, 896, 562}},
-        {256, {0.38, 0.4, 0.57, 0.72, 1.45},  {1370, 1219, 868, 656, 488}},
-        {512, {0.38, 0.4, 0.5, 0.61, 0.99},   {756, 694, 560, 445, 344}},
-    };
     if (g_nforced == ntargets) {                       // bh_swd_set_forms (tests, experiments)
         for (int t = 0; t < ntargets; t++) width[t] = g_forced_forms[t];
         return;
@@ -287,34 +268,55 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
     }
     const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
     const long searches = (long)B * ntargets;
-    auto allowed = [&](const Form &f) {
-        if (f.width == 0) return true;
+    const double scale = 256.0 / (double)cus;                  // the table's chip has 256 CUs
+    auto allowed = [&](int k) {
+        if (bh::kFormWidth[k] == 0) return true;
         if (team_threshold() > 0 && searches > team_threshold()) return false;
-        return bh::swd_team_lds_bytes(Lmax, f.width) <= 160 * 1024;
+        return bh::swd_team_lds_bytes(Lmax, bh::kFormWidth[k]) <= 160 * 1024;
+    };
+    // measured range of form k, its time for s searches (1e300: beyond what a wide team was measured for)
+    auto measured = [&](int k) {
+        int n = bh::kFormSizes;
+        while (n > 1 && bh::kFormMs[regime][k][n - 1] < 0) n--;
+        return n;
+    };
+    auto form_ms = [&](int k, double s) {
+        const float *t = bh::kFormMs[regime][k], *S = bh::kFormSearches;
+        const int n = measured(k);
+        if (s <= S[0]) return (double)t[0];
+        if (s > S[n - 1]) return n < bh::kFormSizes ? 1e300 : (double)t[n - 1] * s / S[n - 1];
+        if (s == S[n - 1]) return (double)t[n - 1];
+        int i = 0;
+        while (S[i + 1] <= s) i++;
+        const double f = (std::log(s) - std::log(S[i])) / (std::log(S[i + 1]) - std::log(S[i]));
+        return t[i] + f * (t[i + 1] - t[i]);
     };
     int uniform = 0;
     double best = 1e300;
     for (int k = 0; k < 8; k++) {
-        const Form &f = forms[k];
-        if (!allowed(f)) continue;
-        const double thr = f.thr[regime] * (double)cus / 256.0;
-        const double cost = std::fmax(f.lat[regime], (double)searches / thr);
+        if (!allowed(k)) continue;
+        const double cost = form_ms(k, (double)searches * scale);
         if (cost < best) { best = cost; uniform = k; }
     }
     int form[bh::BH_NT];
     for (int t = 0; t < ntargets; t++) form[t] = uniform;
     static const bool no_mixed = std::getenv("BH_SWD_NO_MIXED") != nullptr;
-    if (ntargets > 1 && !no_mixed && uniform == 0 && regime <= 3 && (long)B <= 32 * cus && allowed(forms[1])) {
+    if (ntargets > 1 && !no_mixed && uniform == 0 && regime <= 3 && (long)B <= 32 * cus && allowed(1)) {
         double w[bh::BH_NT];
         for (int t = 0; t < ntargets; t++) w[t] = target_weight(targets[t]);
+        // latency (chip mostly idle) and saturation rate (searches per ms) of a form, from the table's ends
+        auto lat = [&](int k) { return (double)bh::kFormMs[regime][k][0]; };
+        auto thr = [&](int k) {
+            const int n = measured(k);
+            return (double)bh::kFormSearches[n - 1] / bh::kFormMs[regime][k][n - 1] / scale;
+        };
         auto cost_of = [&](const int *fm) {
-            double lat = 0.0, sum = 0.0;
+            double l = 0.0, sum = 0.0;
             for (int t = 0; t < ntargets; t++) {
-                const Form &f = forms[fm[t]];
-                lat = std::fmax(lat, f.lat[regime] * w[t]);
-                sum += (double)B * w[t] / (f.thr[regime] * (double)cus / 256.0);
+                l = std::fmax(l, lat(fm[t]) * w[t]);
+                sum += (double)B * w[t] / thr(fm[t]);
             }
-            return std::fmax(lat, sum);
+            return std::fmax(l, sum);
         };
         double cur = cost_of(form);
         for (int pass = 0; pass + 1 < ntargets; pass++) {
@@ -328,7 +330,7 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
             cur = c;
         }
     }
-    for (int t = 0; t < ntargets; t++) width[t] = forms[form[t]].width;
+    for (int t = 0; t < ntargets; t++) width[t] = bh::kFormWidth[form[t]];
 }
 
 int pick_rf_M(int B, int Lmax, int nsamp)
