@@ -246,7 +246,7 @@ def emit(line):
 
 
 # ------------------------------------------------------------------------------------ chain pool
-def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
+def chain_pool_sample(nchains=4096, burnin=200, main_it=100):
     """End-to-end sampler on top of the timed path (not part of `value`): a lock-step pool of
     chains on the tutorial inversion (Rayleigh phase + P-RF, observed data in
     tests/golden/tutorial_observed), chain iterations per second incl. host proposals/acceptance."""
@@ -261,6 +261,10 @@ def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
                       swdnoise_corr=0., rfnoise_sigma=(1e-5, 0.05), swdnoise_sigma=(1e-5, 0.05))
         ip = dict(iter_burnin=burnin, iter_main=main_it, propdist=(0.015, 0.015, 0.015, 0.005, 0.005),
                   acceptance=(40, 100), thickmin=0.1, rcond=1e-5)
+        # a short pool of the same size first: kernel forms loaded on their first launch, helper threads and pinned
+        # buffers are not chain iterations (0.05-0.1 s of a 0.3 s sample when they fell into it)
+        ChainPool(joint, initparams=dict(ip, iter_burnin=6, iter_main=2), modelpriors=priors,
+                  seeds=np.arange(nchains) % 1000, nmodels=9).run()
         pool = ChainPool(joint, initparams=ip, modelpriors=priors, seeds=np.arange(nchains) % 1000)
         t0 = time.perf_counter()
         pool.run()
