@@ -137,7 +137,7 @@ class _Group(object):
     def close(self):
         if self.handle:
             self.lib.bh_chains_destroy(self.handle)
-            self.handle = C.c_void_p()
+            self.handle = None           # (not C.c_void_p(): at interpreter shutdown the module globals are gone)
 
 
 class ChainPool(object):

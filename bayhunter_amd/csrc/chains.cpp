@@ -263,8 +263,12 @@ private:
 
 int default_threads()
 {
-    // the cores this process may run on, at most 16 (a GPU box gives one GPU a 16-core share of a
-    // much larger machine); BH_CHAIN_THREADS overrides
+    // three quarters of the cores this process may run on (at most 16 of them: a GPU box gives one GPU a 16-core
+    // share of a much larger machine, as a CPU quota): the helpers spin between the jobs of an iteration, and with
+    // one spinning thread per core of the quota the HIP runtime's own threads pushed the process over it -- stalls
+    // of 10-80 ms while the quota period ran out, 2.0 against 2.2e6 chain iterations/s at 4096 chains (12 or 8
+    // threads; larger pools are device-bound and do not care; profiles/r03_chain_threads.txt).
+    // BH_CHAIN_THREADS overrides.
     if (const char *e = std::getenv("BH_CHAIN_THREADS")) {
         int v = std::atoi(e);
         if (v > 0) return v;
@@ -273,7 +277,8 @@ int default_threads()
     int n = 0;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
     if (n < 1) n = (int)std::max(1u, std::thread::hardware_concurrency());
-    return std::min(n, 16);
+    n = std::min(n, 16);
+    return std::max(1, n - n / 4);
 }
 
 }  // namespace
