@@ -253,6 +253,15 @@ double target_weight(const bh_swd_target &s)
 // the 64-lane teams up to ~20 000, the lane kernel beyond.  bh_swd_set_kernel / bh_swd_set_forms override;
 // BH_SWD_TEAM_MAX (searches) caps the use of team kernels.
 //
+// Several targets: first the one form that is best for all of them (as above, with B x ntargets searches).  One
+// refinement, where it was measured to pay: the call is latency-bound on the lane kernel -- a few thousand models,
+// every search has a SIMD to itself and the call takes as long as its heaviest target (four targets x 8192
+// ten-layer models, 40 periods: 22.7 ms, the Rayleigh group velocities) -- and the batch is small enough for a team
+// kernel to take that target beside the others (B <= 32 searches per CU, at most 20 layers).  The heaviest target
+// then runs on a team kernel on a second stream if the estimate max(max_t lat w_t, sum_t B w_t / rate) drops by
+// 10 % or more (same example: 17.0 ms).  Nothing else is moved: with more models the teams share SIMDs and lose
+// more than the lane kernel gains, and moves between team forms measured worse throughout (tools/auto_forms.py,
+// tools/forced_forms.py, profiles/r03_mixed_forms.txt).  BH_SWD_NO_MIXED=1 keeps one form per call (A/B).
 void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, long cus, int swd_mode, int *width)
 {
     if (g_nforced == ntargets) {                       // bh_swd_set_forms (tests, experiments)
@@ -301,7 +310,10 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
     int form[bh::BH_NT];
     for (int t = 0; t < ntargets; t++) form[t] = uniform;
     static const bool no_mixed = std::getenv("BH_SWD_NO_MIXED") != nullptr;
-    if (ntargets > 1 && !no_mixed && uniform == 0 && regime <= 3 && (long)B <= 32 * cus && allowed(1)) {
+    // the form the heaviest target moves to: 128-lane teams from seven layers up, 8-lane teams below (of 8-, 64-
+    // and 128-lane teams beside the lane kernel, seven shapes: profiles/r03_mixed_forms.txt, part 4)
+    const int moved = (regime >= 2 && allowed(5)) ? 5 : 1;
+    if (ntargets > 1 && !no_mixed && uniform == 0 && regime <= 3 && (long)B <= 32 * cus && allowed(moved)) {
         double w[bh::BH_NT];
         for (int t = 0; t < ntargets; t++) w[t] = target_weight(targets[t]);
         // latency (chip mostly idle) and saturation rate (searches per ms) of a form, from the table's ends
@@ -324,7 +336,7 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
             for (int t = 0; t < ntargets; t++)
                 if (form[t] == 0 && (worst < 0 || w[t] > w[worst])) worst = t;
             if (worst < 0) break;
-            form[worst] = 1;
+            form[worst] = moved;
             const double c = cost_of(form);
             if (c > 0.9 * cur) { form[worst] = 0; break; }
             cur = c;

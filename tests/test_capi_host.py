@@ -164,7 +164,7 @@ def test_bench_evaluation_counts_are_the_oracles():
 def test_form_plan_moves_the_heaviest_target_of_a_latency_bound_call():
     """bh_swd_plan_forms (host only): one form per call where one form is right -- a handful of models (wide
     teams), a saturated chip (lane kernel), a single target -- and the Rayleigh group velocities of BASELINE cfg3
-    on 8-lane teams beside the lane kernel for the other three targets."""
+    on 128-lane teams (8-lane teams for shallow models) beside the lane kernel for the other three targets."""
     import ctypes as C
     from bayhunter_amd import _lib
     lib = _lib.load()
@@ -179,7 +179,7 @@ def test_form_plan_moves_the_heaviest_target_of_a_latency_bound_call():
         _lib.check(lib.bh_swd_plan_forms(B, L, len(specs), tg, 256, forms))
         return list(forms)
     cfg3 = [(2, 0, 40), (2, 1, 40), (1, 0, 40), (1, 1, 40)]
-    assert plan(8192, 10, cfg3) == [0, 8, 0, 0]
+    assert plan(8192, 10, cfg3) == [0, 128, 0, 0] and plan(8192, 5, cfg3) == [0, 8, 0, 0]
     assert plan(64, 10, cfg3) == [512] * 4 and plan(524288, 10, cfg3) == [0] * 4
     assert plan(8192, 10, [(2, 0, 21)]) == [64] and plan(524288, 10, [(2, 0, 21)]) == [0]
     for B in (1, 64, 1024, 8192, 65536):
