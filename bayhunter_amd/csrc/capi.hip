@@ -472,7 +472,11 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     for (int a = 1; a < nlaunch; a++)
         if (launches[a].weight > launches[0].weight) std::swap(launches[a], launches[0]);
     hipStream_t main_stream = (hipStream_t)stream;
-    hipError_t le = hipMemsetAsync(A.counters, 0, bh::BH_NT * sizeof(unsigned int), main_stream);
+    // the work-queue heads: only the lane kernel and the narrow teams pull searches from a queue (a wide team is one
+    // workgroup per search) -- small pools on wide teams are spared a fill kernel per call
+    bool queued = false;
+    for (int a = 0; a < nlaunch; a++) queued = queued || launches[a].width < 64;
+    hipError_t le = queued ? hipMemsetAsync(A.counters, 0, bh::BH_NT * sizeof(unsigned int), main_stream) : hipSuccess;
     SlotStreams ss;
     if (le == hipSuccess && nlaunch > 1) {
         rc = get_slot_streams(slot, nlaunch - 1, &ss);
