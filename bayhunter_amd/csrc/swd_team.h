@@ -221,13 +221,18 @@ enum { SWD_TEAMW_NT = 64 };       // max trials per round (one per lane of the c
 // 14 c41 15 c42 16 c43 | 17 c51 18 c53   (c25 = c14, c44 = c22, c45 = c12, c52 = c41, c54 = c21, c55 = c11).
 // Until round 3 it was the 25 entries column by column on 30 doubles (one aligned run per lane of the quad
 // chain): 18.3 KB of LDS per 64-lane team -- eight teams per CU, two waves per SIMD where the registers allow
-// three.  With 20 doubles a team takes 12.9 KB: twelve per CU.
+// three.  With 20 doubles (at a pitch of 21, below) a team takes 13.4 KB: twelve per CU.
 enum { SWD_MAT = 20 };
-// Slot s of the store begins at double swd_mat_off(s).  (The lanes of a wave write one matrix each, 8 bytes per
-// store: with a stride of 20 doubles lanes l and l + 8 share their banks and a store takes 8 cycles instead of 2,
-// ~100 cycles per round.  One double of padding per eight slots removes that -- and the irregular stride took the
-// kernels from 142 to 189 VGPRs, i.e. from three waves per SIMD back to two: not worth it.)
-BH_HD int swd_mat_off(int s) { return s * SWD_MAT; }
+// Slot s of the store begins at double swd_mat_off(s): a pitch of 21 doubles, one more than a matrix.  The lanes of
+// a wave write one matrix each, 8 bytes per store, and the quads of the chain read the matrices of different trials
+// side by side: with a pitch of 20 doubles (40 banks) lanes l and l + 8, and the trials of a five-layer model, fall
+// on the same banks (8-way conflicts); 42 banks spread them over all 64 (one 512-lane team 0.602 -> 0.581 ms, four
+// waves 0.693 -> 0.674, 1 024 five-layer searches 0.521 -> 0.516; same box, profiles/r03_ab_pitch.txt).  A 64-lane
+// team then takes 13.4 KB: twelve per CU up to 28 layers, eleven beyond.  (An irregular padding -- one double per
+// eight slots -- took the kernels from 142 to 189 VGPRs; sizing the per-trial arrays by the launch, which would keep
+// twelve teams at any depth, to 168 + scratch.)
+enum { SWD_PITCH = 21 };
+BH_HD int swd_mat_off(int s) { return s * SWD_PITCH; }
 
 // floor(log2(x)) for x >= 1
 BH_DEV int swd_ilog2(int x) { return 31 - __builtin_clz((unsigned)x); }
