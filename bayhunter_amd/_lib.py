@@ -200,6 +200,10 @@ _SIGS = {
     "bh_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "bh_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "bh_stream_synchronize": (C.c_int, [_vp]),
+    "bh_stream_retire": (C.c_int, [_vp]),
+    "bh_stream_create": (C.c_int, [C.POINTER(_vp)]),
+    "bh_stream_destroy": (C.c_int, [_vp]),
+    "bh_rf_cached_tables": (C.c_int, []),
 }
 EXPORTS = sorted(_SIGS)
 

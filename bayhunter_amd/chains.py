@@ -58,6 +58,9 @@ class _CallEvaluator(object):
         logL, misfits = ticket
         return np.ascontiguousarray(logL, dtype=np.float64), np.ascontiguousarray(misfits, dtype=np.float64)
 
+    def release(self, packed):
+        pass
+
 
 class GpuEvaluator(object):
     """Proposals -> (logL, misfits) on the device, one evaluation plan of the library per chain group
@@ -94,6 +97,18 @@ class GpuEvaluator(object):
         if ticket is None:
             return np.zeros(0), np.zeros((0, self.joint.ntargets + 1))
         return ticket.wait()
+
+    def release(self, packed):
+        """Close the plan behind the staging block `packed` (a chain group is done with it)."""
+        for key, plan in list(self._plans.items()):
+            if plan.packed is packed:
+                del self._plans[key]
+                plan.close()
+
+    def close(self):
+        for plan in self._plans.values():
+            plan.close()
+        self._plans = {}
 
 
 class _Group(object):
@@ -134,10 +149,20 @@ class _Group(object):
     def done(self):
         return bool(self.lib.bh_chains_done(self.handle))
 
-    def close(self):
+    def close(self, evaluator=None):
         if self.handle:
             self.lib.bh_chains_destroy(self.handle)
             self.handle = None           # (not C.c_void_p(): at interpreter shutdown the module globals are gone)
+        if evaluator is not None and self.packed is not None:
+            if self.ticket is not None:                  # a batch still in flight: let it land before its plan goes
+                try:
+                    evaluator.collect(self.ticket)
+                except Exception:
+                    pass
+                self.ticket = None
+            if hasattr(evaluator, 'release'):
+                evaluator.release(self.packed)
+            self.packed = self.nlay = self.noise = self.chain = None
 
 
 class ChainPool(object):
@@ -159,6 +184,12 @@ class ChainPool(object):
                  (distributed.shard_range), one process per GPU.  Seeds are drawn for ALL chains
                  first, so chain c is the same chain whatever the number of ranks; chains never
                  talk while sampling, `gather()` collects the sample blocks afterwards.
+
+    Lifetime: a pool holds host threads, pinned memory, device buffers and streams (one evaluation
+    plan per group).  `close()` releases them -- the sample arrays, `chain()`, `weighted()`, `final()`,
+    `save()` and the gathers keep working on a closed pool -- and `with ChainPool(...) as pool:` does it
+    at the end of the block.  The reference's equivalent is MCMC_Optimizer.mp_inversion returning
+    (src/mcmcOptimizer.py:202-283): it can be called again, and so can this.
     """
 
     def __init__(self, targets, initparams=None, modelpriors=None, random_seed=None, nchains=None,
@@ -232,10 +263,32 @@ class ChainPool(object):
         # host acceptance
         self.seconds = dict(propose=0.0, submit=0.0, wait=0.0, accept=0.0)
         self._finished = False
+        self._closed_counters = None
+
+    def close(self):
+        """Release the pool's native resources (idempotent); results stay readable."""
+        groups = getattr(self, 'groups', ())
+        if self._closed_counters is None and groups and all(g.handle for g in groups):
+            self._closed_counters = self.counters()
+        for g in groups:
+            g.close(getattr(self, 'evaluator', None))
+
+    @property
+    def closed(self):
+        return not any(g.handle for g in getattr(self, 'groups', ()))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
-        for g in getattr(self, 'groups', ()):
-            g.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- configuration -----------------------------------------------------------------------
     def _config(self):
@@ -300,6 +353,8 @@ class ChainPool(object):
         """Initial models, then iter_burnin + iter_main iterations of every chain."""
         if self._finished:
             return self
+        if self.closed:
+            raise _lib.BayHunterAmdError("this chain pool has been closed")
         for g in self.groups:
             self._launch(g)                       # initial models of every group in flight
         live = list(self.groups)
@@ -324,6 +379,8 @@ class ChainPool(object):
     # -- results -----------------------------------------------------------------------------
     def counters(self):
         """naccepted[nchains], propdist / accepted / proposed [nchains, 5]."""
+        if self._closed_counters is not None and self.closed:
+            return self._closed_counters
         n = np.zeros(self.nchains, dtype=np.int64)
         pd, acc, pro = (np.zeros((self.nchains, 5)) for _ in range(3))
         for g in self.groups:

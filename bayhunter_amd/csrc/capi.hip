@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 #include "../../include/bayhunter_amd.h"
@@ -84,26 +85,69 @@ int get_twiddles(int nsamp, const double **out)
 
 // Per-frequency constants of the receiver-function kernel (rf_host.h, rf_fill_freq_table): one table per
 // (device, nsamp, fsamp, gauss, tshift), built on the host with the reference's expressions.  A run uses a
-// handful of parameter sets; tables are small (24 bytes per frequency) and live until the process ends
-// (a launch in flight may still read them).
-std::map<std::tuple<int, int, double, double, double>, double *> g_ftab;
+// handful of parameter sets, but a caller of the single-model drop-ins may vary the Gauss width or the time
+// shift per call (a sweep of 24 585 configurations did), so the cache is bounded: beyond kFtabMax tables the
+// least recently used one that no call holds goes.  A table is pinned from the look-up to the launch; hipFree
+// waits for the device, so a launch that was started with the table has finished when it is released.
+constexpr size_t kFtabMax = 64;
+struct FreqTable { double *d = nullptr; unsigned long stamp = 0; int pins = 0; };
+using FreqKey = std::tuple<int, int, double, double, double>;
+std::map<FreqKey, FreqTable> g_ftab;
+unsigned long g_ftab_clock = 0;
 
-int get_freq_table(const bh::RfLaunch &P, double fsamp, const double **out)
+struct FreqTablePin {               // releases the pin when the call that looked the table up is done with it
+    FreqTable *t = nullptr;
+    ~FreqTablePin()
+    {
+        if (!t) return;
+        std::lock_guard<std::mutex> lock(g_tw_mutex);
+        t->pins--;
+    }
+};
+
+int get_freq_table(const bh::RfLaunch &P, double fsamp, const double **out, FreqTablePin *pin)
 {
     int dev = 0;
     BH_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_tw_mutex);
-    auto key = std::make_tuple(dev, P.nsamp, fsamp, P.gauss, P.tshift);
-    auto it = g_ftab.find(key);
-    if (it == g_ftab.end()) {
-        std::vector<double> tab((size_t)bh::RF_FTAB * P.nfreq);
-        bh::rf_fill_freq_table(P, tab.data());
-        double *d = nullptr;
-        BH_HIP(hipMalloc((void **)&d, tab.size() * sizeof(double)));
-        BH_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-        it = g_ftab.emplace(key, d).first;
+    const FreqKey key = std::make_tuple(dev, P.nsamp, fsamp, P.gauss, P.tshift);
+    std::vector<double> tab;
+    {
+        std::lock_guard<std::mutex> lock(g_tw_mutex);
+        auto it = g_ftab.find(key);
+        if (it != g_ftab.end()) {
+            it->second.stamp = ++g_ftab_clock;
+            it->second.pins++;
+            pin->t = &it->second;                 // (std::map: the address of a value is stable)
+            *out = it->second.d;
+            return BH_OK;
+        }
     }
-    *out = it->second;
+    // not cached: table and upload outside the lock (two threads may both build one; the second is dropped)
+    tab.resize((size_t)bh::RF_FTAB * P.nfreq);
+    bh::rf_fill_freq_table(P, tab.data());
+    double *d = nullptr;
+    BH_HIP(hipMalloc((void **)&d, tab.size() * sizeof(double)));
+    hipError_t ce = hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) { (void)hipFree(d); return fail_hip(ce, "hipMemcpy(frequency table)"); }
+    std::vector<double *> evicted;
+    {
+        std::lock_guard<std::mutex> lock(g_tw_mutex);
+        auto ins = g_ftab.emplace(key, FreqTable{});
+        if (ins.second) ins.first->second.d = d; else evicted.push_back(d);
+        ins.first->second.stamp = ++g_ftab_clock;
+        ins.first->second.pins++;
+        pin->t = &ins.first->second;
+        *out = ins.first->second.d;
+        while (g_ftab.size() > kFtabMax) {
+            auto victim = g_ftab.end();
+            for (auto jt = g_ftab.begin(); jt != g_ftab.end(); ++jt)
+                if (jt->second.pins == 0 && (victim == g_ftab.end() || jt->second.stamp < victim->second.stamp)) victim = jt;
+            if (victim == g_ftab.end()) break;    // every table is held by a call in progress
+            evicted.push_back(victim->second.d);
+            g_ftab.erase(victim);
+        }
+    }
+    for (double *e : evicted) (void)hipFree(e);   // (synchronises with the device)
     return BH_OK;
 }
 
@@ -128,6 +172,14 @@ struct DevState {
     hipStream_t aux[kAuxStreams] = {nullptr, nullptr};
     hipEvent_t fork[kQueueSlots], join[kQueueSlots][kAuxStreams];
     bool forked[kQueueSlots];
+    // The stream `done` / `fork` were last recorded on.  A HIP event keeps a pointer to that stream and
+    // hipEventQuery / hipEventSynchronize / hipStreamWaitEvent look at its capture state: an event must not
+    // outlive the stream it was recorded on.  The caller's stream is the caller's to destroy, so the owner of a
+    // stream retires it first (bh_stream_retire: evaluation plans do, evalplan.hip plan_free) and the slot's
+    // events are destroyed with it.  (Round 3 did not: a plan's streams died under recorded slot events, and a
+    // later launch that claimed such a slot queried freed memory -- "operation not permitted when stream is
+    // capturing" in the driver's bench run)
+    hipStream_t done_stream[kQueueSlots], fork_stream[kQueueSlots];
 };
 std::mutex g_dev_mutex;
 std::map<int, DevState> g_dev;
@@ -143,7 +195,10 @@ int get_queue_slot(unsigned int **slot, int *slot_index, int *resident_waves)
         hipDeviceProp_t prop;
         BH_HIP(hipGetDeviceProperties(&prop, dev));
         d.cus = prop.multiProcessorCount;
-        for (int i = 0; i < kQueueSlots; i++) d.used[i] = d.claimed[i] = d.forked[i] = false;
+        for (int i = 0; i < kQueueSlots; i++) {
+            d.used[i] = d.claimed[i] = d.forked[i] = false;
+            d.done_stream[i] = d.fork_stream[i] = nullptr;
+        }
         if (const char *e = std::getenv("BH_SWD_QUEUE_SLOTS")) {
             int v = std::atoi(e);
             if (v >= 1 && v <= kQueueSlots) d.nslots = v;
@@ -194,6 +249,7 @@ int release_queue_slot(int i, hipStream_t stream)
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     DevState &d = g_dev[dev];
     hipError_t e = hipEventRecord(d.done[i], stream);
+    d.done_stream[i] = stream;
     d.claimed[i] = false;
     if (e != hipSuccess) return fail_hip(e, "hipEventRecord(queue slot)");
     return BH_OK;
@@ -221,6 +277,55 @@ int get_slot_streams(int i, int naux, SlotStreams *out)
     }
     out->fork = d.fork[i];
     for (int k = 0; k < kAuxStreams; k++) { out->aux[k] = d.aux[k]; out->join[k] = d.join[i][k]; }
+    return BH_OK;
+}
+
+// the fork event of slot `i` (claimed by the calling thread) was recorded on `stream`
+void note_fork_stream(int i, hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    g_dev[dev].fork_stream[i] = stream;
+}
+
+// Everything the library has recorded on `stream` is finished and forgotten: the caller may destroy it.
+int retire_stream(hipStream_t stream)
+{
+    if (!stream) return BH_OK;                       // the null stream is never destroyed
+    BH_HIP(hipStreamSynchronize(stream));
+    std::unique_lock<std::mutex> lock(g_dev_mutex);
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    for (auto &kv : g_dev) {
+        DevState &d = kv.second;
+        if (!d.queue) continue;
+        for (int i = 0; i < kQueueSlots; i++) {
+            // A slot another thread holds for a launch on ITS stream may still carry this stream's event (that
+            // thread may even be waiting for it -- it completed with the synchronisation above): wait until the
+            // slot is released, by then its event has been recorded anew on the other stream.
+            while (d.claimed[i] && ((d.used[i] && d.done_stream[i] == stream) || (d.forked[i] && d.fork_stream[i] == stream))) {
+                lock.unlock();
+                std::this_thread::yield();
+                lock.lock();
+            }
+            if (d.claimed[i]) continue;
+            if (d.used[i] && d.done_stream[i] == stream) {
+                note(hipEventDestroy(d.done[i]));
+                d.used[i] = false;
+                d.done_stream[i] = nullptr;
+            }
+            if (d.forked[i] && d.fork_stream[i] == stream) {
+                // the join events were recorded on the library's own streams, which live as long as the
+                // process; they go with the fork event only to keep the slot's three events one unit
+                note(hipEventDestroy(d.fork[i]));
+                for (int k = 0; k < kAuxStreams; k++) note(hipEventDestroy(d.join[i][k]));
+                d.forked[i] = false;
+                d.fork_stream[i] = nullptr;
+            }
+        }
+    }
+    if (first != hipSuccess) return fail_hip(first, "hipEventDestroy(retired stream)");
     return BH_OK;
 }
 
@@ -477,11 +582,14 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     bool queued = false;
     for (int a = 0; a < nlaunch; a++) queued = queued || launches[a].width < 64;
     hipError_t le = queued ? hipMemsetAsync(A.counters, 0, bh::BH_NT * sizeof(unsigned int), main_stream) : hipSuccess;
-    SlotStreams ss;
+    SlotStreams ss{};
+    bool forked = false;                 // the aux streams and the slot's fork/join events are in `ss`
     if (le == hipSuccess && nlaunch > 1) {
         rc = get_slot_streams(slot, nlaunch - 1, &ss);
         if (rc) { release_queue_slot(slot, main_stream); return rc; }
+        forked = true;
         le = hipEventRecord(ss.fork, main_stream);            // the models (and the zeroed counters) are ready
+        note_fork_stream(slot, main_stream);
     }
     for (int a = 0; a < nlaunch && le == hipSuccess; a++) {
         const Launch &l = launches[a];
@@ -509,7 +617,7 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     // the caller's stream continues when every launch is done -- also after a failed launch, for those that
     // were started
     // (an event that was not recorded in this call is complete: waiting for it costs nothing)
-    for (int a = 1; a < nlaunch; a++) {
+    for (int a = 1; a < nlaunch && forked; a++) {
         hipError_t we = hipStreamWaitEvent(main_stream, ss.join[a - 1], 0);
         if (le == hipSuccess) le = we;
     }
@@ -614,7 +722,8 @@ static int rf_launch_common(int B, int Lmax, int model_stride, const int *nlay, 
     A.out_fz = out_fz; A.out_fr = out_fr;
     rc = get_twiddles(n, &A.tw);
     if (rc) return rc;
-    rc = get_freq_table(A.P, par->fsamp, &A.ftab);
+    FreqTablePin pin;                              // held until the launch below has been queued
+    rc = get_freq_table(A.P, par->fsamp, &A.ftab, &pin);
     if (rc) return rc;
     A.B = B; A.mstride = model_stride; A.nlay = nlay; A.h = h; A.vp = vp; A.vs = vs; A.rho = rho; A.qp = qp; A.qs = qs;
     A.out = out;
@@ -859,6 +968,11 @@ int bh_free(void *dptr)
     BH_HIP(hipFree(dptr));
     return BH_OK;
 }
+int bh_rf_cached_tables(void)
+{
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    return (int)g_ftab.size();
+}
 int bh_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
     BH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -872,6 +986,25 @@ int bh_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
 int bh_stream_synchronize(void *stream)
 {
     BH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BH_OK;
+}
+int bh_stream_retire(void *stream) { return retire_stream((hipStream_t)stream); }
+int bh_stream_create(void **stream)
+{
+    if (!stream) return fail_arg("stream is NULL");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    BH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return BH_OK;
+}
+int bh_stream_destroy(void *stream)
+{
+    if (!stream) return fail_arg("the null stream cannot be destroyed");
+    int rc = retire_stream((hipStream_t)stream);
+    if (rc) return rc;
+    BH_HIP(hipStreamDestroy((hipStream_t)stream));
     return BH_OK;
 }
 

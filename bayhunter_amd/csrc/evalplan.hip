@@ -19,6 +19,7 @@
 #include "../../include/bayhunter_amd.h"
 
 namespace bh { int fail_arg_(const char *what); int fail_hip_(int e, const char *what); }
+extern "C" const char *bh_last_error(void);
 
 namespace {
 
@@ -52,6 +53,17 @@ __global__ void interp_kernel(int B, double *out, int stride, Interp T)
     row[T.dst_off + i] = T.last[i] ? f[T.n_src - 1] : y;
 }
 
+// A plan without dispersion targets has no kernel that raises BH_MODEL_BAD_DEPTH: the flag of a model whose
+// layer count is outside 1..L (its receiver-function row is NaN) is set here, as ForwardEngine.run does.
+__global__ void depth_flags_kernel(int n, const int *nlay, int L, int nflags, int *err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int nl = nlay[i];
+    err[(long)i * nflags] = (nl < 1 || nl > L) ? BH_MODEL_BAD_DEPTH : 0;
+    for (int k = 1; k < nflags; k++) err[(long)i * nflags + k] = 0;
+}
+
 __global__ void iota_kernel(int n, int *v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,7 +91,9 @@ struct bh_eval_plan {
     size_t sort_bytes = 0, like_bytes = 0, swd_bytes = 0;
     hipStream_t st = nullptr, side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, done = nullptr;
-    int last_count = 0;
+    int last_count = 0;           // models of the submission `done` belongs to (set once `done` is recorded)
+    bool failed = false;          // the last submission returned an error: nothing to wait for, no results
+    std::string failure;
 };
 
 static void plan_free(bh_eval_plan *p)
@@ -98,6 +112,9 @@ static void plan_free(bh_eval_plan *p)
     if (p->fork) (void)hipEventDestroy(p->fork);
     if (p->join) (void)hipEventDestroy(p->join);
     if (p->done) (void)hipEventDestroy(p->done);
+    // the library's own events on these streams (work-queue slot guards, capi.hip) go before the streams do
+    if (p->st) (void)bh_stream_retire(p->st);
+    if (p->side) (void)bh_stream_retire(p->side);
     if (p->st) (void)hipStreamDestroy(p->st);
     if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
@@ -233,12 +250,9 @@ int bh_eval_buffers(bh_eval_plan *p, double **packed, int **nlay, double **noise
     return BH_OK;
 }
 
-int bh_eval_submit(bh_eval_plan *p, int count)
+// the launches of one submission; `forked` tells the caller whether the side stream was made to wait
+static int submit_batch(bh_eval_plan *p, int count, bool *forked)
 {
-    if (!p) return bh::fail_arg_("plan is NULL");
-    if (count < 0 || count > p->rows) return bh::fail_arg_("count out of range");
-    p->last_count = count;
-    if (count == 0) return BH_OK;
     EP_HIP(hipSetDevice(p->dev));
     const int L = p->Lmax, T = p->T;
     const int *hnlay = (const int *)(p->hblock + p->off_nlay);
@@ -266,6 +280,7 @@ int bh_eval_submit(bh_eval_plan *p, int count)
     if (overlap) {
         EP_HIP(hipEventRecord(p->fork, p->st));
         EP_HIP(hipStreamWaitEvent(p->side, p->fork, 0));
+        *forked = true;
     }
     if (p->nswd) {
         const int *order = nullptr;
@@ -285,7 +300,9 @@ int bh_eval_submit(bh_eval_plan *p, int count)
             EP_HIP(hipGetLastError());
         }
     } else {
-        EP_HIP(hipMemsetAsync(p->err, 0, (size_t)count * p->nflags * sizeof(int), p->st));
+        hipLaunchKernelGGL(depth_flags_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, p->st, count, dnlay,
+                           Leff, p->nflags, p->err);
+        EP_HIP(hipGetLastError());
     }
     hipStream_t rst = overlap ? p->side : p->st;
     for (const bh_rf_params &r : p->rf)
@@ -294,6 +311,7 @@ int bh_eval_submit(bh_eval_plan *p, int count)
     if (overlap) {
         EP_HIP(hipEventRecord(p->join, p->side));
         EP_HIP(hipStreamWaitEvent(p->st, p->join, 0));
+        *forked = false;                  // joined
     }
     double *logL = p->dres, *mis = p->dres + count;
     if ((rc = bh_likelihood_batch(count, T, p->like.data(), p->out, p->row, p->err, p->nflags, p->yobs, dnoise, p->aux,
@@ -305,9 +323,36 @@ int bh_eval_submit(bh_eval_plan *p, int count)
     return BH_OK;
 }
 
+int bh_eval_submit(bh_eval_plan *p, int count)
+{
+    if (!p) return bh::fail_arg_("plan is NULL");
+    if (count < 0 || count > p->rows) return bh::fail_arg_("count out of range");
+    p->failed = false;
+    p->last_count = 0;
+    if (count == 0) return BH_OK;
+    bool forked = false;
+    const int rc = submit_batch(p, count, &forked);
+    if (rc != BH_OK) {
+        // Nothing of this submission may be mistaken for a result: bh_eval_wait reports the failure instead of
+        // finding a stale (or never recorded, hence "complete") event.  What was queued is drained: the side stream
+        // may already be waiting on `fork`, so the main stream joins it before the plan is used or freed.
+        p->failed = true;
+        p->failure = bh_last_error();
+        if (forked && hipEventRecord(p->join, p->side) == hipSuccess) (void)hipStreamWaitEvent(p->st, p->join, 0);
+        bh::fail_arg_(p->failure.c_str());           // (the calls above may have replaced the message)
+        return rc;
+    }
+    p->last_count = count;                            // only now: `done` has been recorded for this batch
+    return BH_OK;
+}
+
 int bh_eval_wait(bh_eval_plan *p, int *count)
 {
     if (!p) return bh::fail_arg_("plan is NULL");
+    if (p->failed) {
+        if (count) *count = 0;
+        return bh::fail_arg_(("the last bh_eval_submit of this plan failed: " + p->failure).c_str());
+    }
     if (p->last_count > 0) EP_HIP(hipEventSynchronize(p->done));
     if (count) *count = p->last_count;
     return BH_OK;

@@ -21,7 +21,11 @@ class EvalPlan(object):
     """`layout` = JointTarget.batch_layout().  Host views of the plan's pinned staging block:
     packed[rows, 4, Lmax], nlay[rows], noise[rows, 2*ntargets], chain[rows]; `submit(count)` evaluates
     the first `count` rows, `wait()` returns (logL[count], misfits[count, ntargets+1]) -- views that stay
-    valid until the next submit."""
+    valid until the next submit.
+
+    A plan owns device memory, pinned host memory, two streams and events: `close()` it (or use it as a
+    context manager) when the sampler is done with it.  `__del__` only backs that up -- when the interpreter
+    collects an object is not something to hang device resources on."""
 
     def __init__(self, layout, max_models, Lmax, use_mfma=True):
         self.lib = _lib.load()
@@ -47,19 +51,39 @@ class EvalPlan(object):
         self.chain = _view(p[3], C.c_int32, R)
         self._results = _view(p[4], C.c_double, R * (T + 2))
 
+    def _live(self):
+        if not self.handle:
+            raise _lib.BayHunterAmdError("this evaluation plan has been closed")
+        return self.handle
+
     def submit(self, count):
-        _lib.check(self.lib.bh_eval_submit(self.handle, int(count)))
+        _lib.check(self.lib.bh_eval_submit(self._live(), int(count)))
 
     def wait(self):
+        self._live()
         n = C.c_int(0)
         _lib.check(self.lib.bh_eval_wait(self.handle, C.byref(n)))
         n, T = n.value, self.T
         return self._results[:n], self._results[n:n * (T + 2)].reshape(n, T + 1)
 
     def close(self):
-        if self.handle:
-            self.lib.bh_eval_destroy(self.handle)
-            self.handle = C.c_void_p()
+        """Wait for the plan's streams, then free everything it owns (idempotent).  The host views
+        (packed, nlay, noise, chain, results) point into freed pinned memory afterwards and are dropped."""
+        h, self.handle = getattr(self, 'handle', None), None
+        if h:
+            self.packed = self.nlay = self.noise = self.chain = self._results = None
+            self.lib.bh_eval_destroy(h)
+
+    @property
+    def closed(self):
+        return not self.handle
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
         try:

@@ -206,24 +206,39 @@ def launch_ranks(args):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                       text=True))
-    out0 = procs[0].communicate()[0]
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()                                  # the exact PID this launcher started
-            rcs.append(p.wait())
-    if any(rcs):
+    # Rank 0's stdout is drained by a thread while ALL ranks are polled: a rank that dies before the rendezvous (no
+    # GPU visible, import error) must end the run at once, not leave rank 0 sitting in init_process_group until
+    # torch's own timeout of several minutes.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get('BH_BENCH_LAUNCH_TIMEOUT', 1500))
+    deadline = time.time() + limit
+    failed = None
+    while failed is None:
+        rcs = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in rcs):
+            failed = 'rank exit codes %s' % rcs
+        elif all(rc == 0 for rc in rcs):
+            break
+        elif time.time() > deadline:
+            failed = 'no result after %.0f s (rank exit codes so far %s)' % (limit, rcs)
+        else:
+            time.sleep(0.05)
+    if failed:
         for p in procs:
             if p.poll() is None:
-                p.kill()
-        sys.stderr.write('bench.py launcher: rank exit codes %s\n' % rcs)
-        sys.stdout.write(out0)
-        sys.exit(1)
+                p.kill()                              # the exact PIDs this launcher started
+        for p in procs:
+            p.wait()
+    reader.join(timeout=10)
+    out0 = ''.join(c for c in chunks if c)
     sys.stdout.write(out0)
     sys.stdout.flush()
+    if failed:
+        sys.stderr.write('bench.py launcher: %s\n' % failed)
+        sys.exit(1)
 
 
 _REAL_STDOUT = None
@@ -246,43 +261,153 @@ def emit(line):
 
 
 # ------------------------------------------------------------------------------------ chain pool
+CHAIN_IP = dict(propdist=(0.015, 0.015, 0.015, 0.005, 0.005), acceptance=(40, 100), thickmin=0.1, rcond=1e-5)
+# The sampler's workloads (not part of `value`): the tutorial joint inversion (Rayleigh phase + P-RF, observed data in
+# tests/golden/tutorial_observed; free vp/vs and noise).  `layers` is the reference's prior on the number of layers
+# above the half-space (src/defaults/defaults.ini): (1, 14) = models of 2..15 layers (BASELINE cfg4: "15-layer, 64
+# chains/GPU"), (1, 30) = 2..31 layers (cfg5: "transdimensional, 1-30 layers ragged, per-GPU chain pools").
+CHAIN_WORKLOADS = {
+    'tutorial': dict(layers=(1, 20), chains_per_gpu=4096, burnin=100, main=50),
+    'cfg4': dict(layers=(1, 14), chains_per_gpu=64, burnin=100, main=50),
+    'cfg5': dict(layers=(1, 30), chains_per_gpu=4096, burnin=100, main=50),
+}
+
+
+def chain_setup(layers):
+    from bayhunter_amd import targets as T
+    d = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
+    sw, rf = np.loadtxt(os.path.join(d, 'st3_rdispph.dat')), np.loadtxt(os.path.join(d, 'st3_prf.dat'))
+    joint = T.JointTarget([T.RayleighDispersionPhase(sw[:, 0], sw[:, 1]), T.PReceiverFunction(rf[:, 0], rf[:, 1])])
+    priors = dict(vpvs=(1.4, 2.1), layers=layers, vs=(2, 5), z=(0, 60), mohoest=None, rfnoise_corr=0.9,
+                  swdnoise_corr=0., rfnoise_sigma=(1e-5, 0.05), swdnoise_sigma=(1e-5, 0.05))
+    return joint, priors
+
+
 def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
-    """End-to-end sampler on top of the timed path (not part of `value`): a lock-step pool of
-    chains on the tutorial inversion (Rayleigh phase + P-RF, observed data in
-    tests/golden/tutorial_observed), chain iterations per second incl. host proposals/acceptance."""
-    try:
-        import torch
-        from bayhunter_amd import targets as T
-        from bayhunter_amd.chains import ChainPool
-        d = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
-        sw, rf = np.loadtxt(os.path.join(d, 'st3_rdispph.dat')), np.loadtxt(os.path.join(d, 'st3_prf.dat'))
-        joint = T.JointTarget([T.RayleighDispersionPhase(sw[:, 0], sw[:, 1]), T.PReceiverFunction(rf[:, 0], rf[:, 1])])
-        priors = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), mohoest=None, rfnoise_corr=0.9,
-                      swdnoise_corr=0., rfnoise_sigma=(1e-5, 0.05), swdnoise_sigma=(1e-5, 0.05))
-        ip = dict(iter_burnin=burnin, iter_main=main_it, propdist=(0.015, 0.015, 0.015, 0.005, 0.005),
-                  acceptance=(40, 100), thickmin=0.1, rcond=1e-5)
-        # a short pool of the same size first: kernel forms loaded on their first launch, helper threads and pinned
-        # buffers are not chain iterations (0.05-0.1 s of a 0.3 s sample when they fell into it)
-        ChainPool(joint, initparams=dict(ip, iter_burnin=6, iter_main=2), modelpriors=priors,
-                  seeds=np.arange(nchains) % 1000, nmodels=9).run()
-        # three samples, the best one reported (all three in the record): single stalls of 10-80 ms on the host side
-        # -- the box's CPU quota period running out under the pool's spinning helpers and the HIP runtime's threads
-        # -- are a third of one 0.3 s sample when they fall into it
-        runs = []
-        for _ in range(3):
-            pool = ChainPool(joint, initparams=ip, modelpriors=priors, seeds=np.arange(nchains) % 1000)
+    """End-to-end sampler on top of the timed path, one GPU: a lock-step pool of chains on the tutorial
+    inversion, chain iterations per second incl. host proposals/acceptance.  Every pool is closed before the
+    next one is made (ChainPool.close: its evaluation plans retire their streams)."""
+    import torch
+    from bayhunter_amd.chains import ChainPool
+    if os.environ.get('BH_BENCH_INJECT_FAILURE') == 'chain_pool':        # test hook: a leg that fails must be seen
+        raise RuntimeError('injected failure of the chain-pool leg')
+    joint, priors = chain_setup(CHAIN_WORKLOADS['tutorial']['layers'])
+    ip = dict(CHAIN_IP, iter_burnin=burnin, iter_main=main_it)
+    seeds = np.arange(nchains) % 1000
+    # a short pool of the same size first: kernel forms loaded on their first launch, helper threads and pinned
+    # buffers are not chain iterations (0.05-0.1 s of a 0.3 s sample when they fell into it)
+    with ChainPool(joint, initparams=dict(ip, iter_burnin=6, iter_main=2), modelpriors=priors, seeds=seeds, nmodels=9) as warm:
+        warm.run()
+    # three samples, the best one reported (all three in the record): single stalls of 10-80 ms on the host side
+    # -- the box's CPU quota period running out under the pool's spinning helpers and the HIP runtime's threads
+    # -- are a third of one 0.3 s sample when they fall into it
+    runs = []
+    for _ in range(3):
+        with ChainPool(joint, initparams=ip, modelpriors=priors, seeds=seeds) as pool:
             t0 = time.perf_counter()
             pool.run()
             torch.cuda.synchronize()
-            runs.append((time.perf_counter() - t0, pool))
-        dt, pool = min(runs, key=lambda r: r[0])
-        return {"value": nchains * (burnin + main_it) / dt, "unit": "chain iterations/s", "nchains": nchains,
-                "iterations": burnin + main_it, "models_evaluated": int(pool.evaluated),
-                "samples": [round(nchains * (burnin + main_it) / r[0]) for r in runs],
-                "workload": "tutorial joint inversion (rdispph + prf), free vp/vs and noise, 2-21 layers",
-                "host_seconds": {k: round(v, 4) for k, v in pool.seconds.items()}}
-    except Exception as e:            # the sample must never take the benchmark line down
-        return {"value": None, "error": repr(e)}
+            runs.append((time.perf_counter() - t0, int(pool.evaluated), dict(pool.seconds)))
+    dt, evaluated, seconds = min(runs, key=lambda r: r[0])
+    return {"ok": True, "value": nchains * (burnin + main_it) / dt, "unit": "chain iterations/s", "nchains": nchains,
+            "iterations": burnin + main_it, "models_evaluated": evaluated,
+            "samples": [round(nchains * (burnin + main_it) / r[0]) for r in runs],
+            "workload": "tutorial joint inversion (rdispph + prf), free vp/vs and noise, 2-21 layers",
+            "host_seconds": {k: round(v, 4) for k, v in seconds.items()}}
+
+
+def chain_digest(blocks):
+    """sha256 over the sample blocks in global chain order (models, likes, iter, noise, vpvs, naccepted): equal for
+    the same seeds whatever the number of ranks."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in ('models', 'likes', 'iter', 'noise', 'vpvs', 'naccepted'):
+        h.update(np.ascontiguousarray(blocks[k]).tobytes())
+    return h.hexdigest()[:16]
+
+
+def sharded_chain_pools(rank, world, ranks, backend):
+    """N > 1: the sampler as BASELINE.json words it -- cfg4 (64 chains per GPU, models of up to 15 layers) and cfg5
+    (per-GPU pools, ragged 2-31 layers) with the chains block-sharded over the ranks and NO collective while
+    sampling (reference: one process per chain, src/mcmcOptimizer.py:238-252) -- and then the one exchange the
+    reference has: the per-chain sample blocks (its shared arrays, src/mcmcOptimizer.py:92-125, merged by
+    src/Plotting.py:161-262) gathered over the process group (RCCL with backend nccl): to the root, raw and
+    thinned, and as an all-gather for comparison.  Returns (chain_pool_sharded, gather) for rank 0's line."""
+    import torch
+    import torch.distributed as dist
+    from bayhunter_amd.chains import ChainPool
+    from bayhunter_amd.distributed import gather_rows, gather_rows_to_root
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+
+    def sync():
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
+
+    def timed(fn):
+        ranks.barrier(); sync()
+        t0 = time.perf_counter()
+        out = fn()
+        sync(); ranks.barrier()
+        return out, ranks.max(time.perf_counter() - t0)
+
+    pools_rec, gather_rec = {}, {}
+    for name in ('cfg4', 'cfg5'):
+        wl = CHAIN_WORKLOADS[name]
+        joint, priors = chain_setup(wl['layers'])
+        ip = dict(CHAIN_IP, iter_burnin=wl['burnin'], iter_main=wl['main'])
+        total = wl['chains_per_gpu'] * world
+        seeds = np.arange(total) % 1000
+        shard = (rank, world)
+        with ChainPool(joint, initparams=dict(ip, iter_burnin=6, iter_main=2), modelpriors=priors, seeds=seeds,
+                       nmodels=9, shard=shard) as warm:
+            warm.run()
+        best = None
+        for _ in range(3 if name == 'cfg4' else 2):
+            pool = ChainPool(joint, initparams=ip, modelpriors=priors, seeds=seeds, shard=shard)
+            _, dt = timed(lambda: pool.run())
+            pool.close()
+            if best is None or dt < best[0]:
+                best = (dt, pool)
+        dt, pool = best
+        its = wl['burnin'] + wl['main']
+        evaluated = ranks.all_floats(float(pool.evaluated))
+        pools_rec[name] = {
+            "value": total * its / dt, "unit": "chain iterations/s", "chains_per_gpu": wl['chains_per_gpu'],
+            "nchains": total, "iterations": its, "seconds": dt, "models_evaluated": int(sum(evaluated)),
+            "layers_prior": list(wl['layers']), "sharding": "chains block-partitioned over ranks, no collective while sampling",
+            "workload": "tutorial joint inversion (rdispph + prf), free vp/vs and noise, models of 2-%d layers" % (wl['layers'][1] + 1)}
+        # -- the exchange: this pool's sample blocks over the process group
+        width = pool.models.shape[2] + pool.misfits.shape[2] + 1 + pool.noise.shape[2] + 1
+        payload = np.concatenate([pool.models, pool.misfits, pool.likes[..., None], pool.noise, pool.vpvs[..., None]],
+                                 axis=2).astype(np.float32)          # SURVEY section 5: rows x width float32
+        t_payload = torch.from_numpy(payload).to(dev)
+        nbytes_rank = payload.nbytes
+        gather_rows_to_root(t_payload, total)                         # first-use costs of the transport (untimed)
+        full, t_root = timed(lambda: gather_rows_to_root(t_payload, total))
+        _, t_all = timed(lambda: gather_rows(t_payload, total))
+        blocks, t_blocks = timed(lambda: pool.gather())
+        maxmodels = 50
+        thinned, t_thin = timed(lambda: pool.gather_final(maxmodels))
+        rec = {
+            "payload": "%d chains x %d rows x %d float32 per rank (models | misfits | likes | noise | vpvs)" % (
+                pool.nchains, pool.nmodels, width),
+            "bytes_per_rank": nbytes_rank, "bytes_received_by_root": nbytes_rank * (world - 1), "backend": backend,
+            "to_root": {"ms": t_root * 1e3, "GB/s": nbytes_rank * (world - 1) / max(t_root, 1e-9) / 1e9,
+                        "how": "every rank sends its block once, point to point (distributed.gather_rows_to_root)"},
+            "all_gather": {"ms": t_all * 1e3, "GB/s": nbytes_rank * (world - 1) * world / max(t_all, 1e-9) / 1e9,
+                           "how": "padded fixed-shape all_gather, every rank ends with everything (distributed.gather_rows)"},
+            "ChainPool.gather": {"ms": t_blocks * 1e3, "note": "the six arrays one by one from host memory, incl. the copies to and from the device"},
+            "ChainPool.gather_final": {"ms": t_thin * 1e3, "maxmodels": maxmodels,
+                                       "note": "residence-time weighting + thinning on every rank (host), then ragged blocks to the root"},
+        }
+        if rank == 0:
+            assert full.shape[0] == total and len(thinned) == total
+            rec["ChainPool.gather_final"]["rows_at_root"] = int(sum(t.shape[0] for t in thinned))
+            rec["chains_sha256"] = chain_digest(blocks)
+            rec["accepted_total"] = int(blocks['naccepted'].sum())
+        gather_rec[name] = rec
+        del t_payload, full
+    return pools_rec, gather_rec
 
 
 # -------------------------------------------------------------------------------- one workload
@@ -487,6 +612,8 @@ def main():
                  % (args.gpus, world, args.gpus, args.gpus))
     claim_stdout()                               # from here on this process is a rank: stdout = the one JSON line
     if args.probe_ranks:                         # launcher / rendezvous check without a GPU (tests)
+        if os.environ.get('BH_BENCH_PROBE_DIE_RANK') == str(rank):      # test hook: a rank that never reaches the rendezvous
+            sys.exit(3)
         import torch.distributed as dist
         seen = [None] * world
         if world > 1:
@@ -575,6 +702,13 @@ def main():
         for c in CONFIG_ORDER:
             cfg_runs.append(run_workload(c, WORKLOADS[c]['B'], rank, ranks, 0, 3, serial=args.serial, budget_s=0.6))
 
+    # N > 1 (or the one-rank rehearsal of its code): the sharded sampler and the gather of its sample blocks --
+    # collectives, so every rank takes part
+    sharded = None
+    if use_dist and headline and not args.no_chain_pool:
+        sharded = sharded_chain_pools(rank, world, ranks, backend)
+
+    exit_code = 0
     if rank == 0:
         lib_hash = bhlib.loaded_hash()
         dom, swd, rf, flop_eval = rooflines(head, lib_hash)
@@ -621,12 +755,29 @@ def main():
                     "hbm_frac": d['hbm']['frac'], "err_models": r['nerr'],
                     "cpu_baseline": cpu.get(r['name'])}
             res["configs"] = cfgs
-        if world == 1 and headline and not args.no_chain_pool:
-            res["chain_pool"] = chain_pool_sample()
+        if sharded is not None:
+            res["chain_pool_sharded"], res["gather"] = sharded
+        failed_legs = []
+        if world == 1 and not use_dist and headline and not args.no_chain_pool:
+            # A failing leg must be seen: the line is still emitted (it carries the error) and the process then exits
+            # non-zero -- after a library error the state of the process is unknown, the run is not a healthy one.
+            try:
+                res["chain_pool"] = chain_pool_sample()
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                res["chain_pool"] = {"ok": False, "value": None, "error": repr(e)}
+                failed_legs.append('chain_pool')
+        res["ok"] = not failed_legs
         emit(json.dumps(res))
+        if failed_legs:
+            sys.stderr.write('bench.py: failed legs: %s\n' % ', '.join(failed_legs))
+            exit_code = 1
     if use_dist:
         dist.barrier() if backend != 'nccl' else dist.barrier(device_ids=[dev])
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == '__main__':

@@ -388,6 +388,20 @@ int bh_free(void *dptr);
 int bh_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int bh_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int bh_stream_synchronize(void *stream);
+/* Diagnostic: per-frequency constant tables of the receiver-function kernel currently cached (one per
+ * (device, nsamp, fsamp, gauss, tshift); bounded, least recently used first out). */
+int bh_rf_cached_tables(void);
+/* Streams are the caller's.  The batched entry points record library events on the stream they are given (the
+ * guards of the dispersion kernels' work-queue slots); a HIP event refers to the stream it was last recorded on,
+ * so before DESTROYING a stream that was ever passed to this library call bh_stream_retire(stream): it waits for
+ * the stream's work and drops every event the library recorded on it.  (Not needed for the null stream nor for
+ * streams that live as long as the process, e.g. the pooled streams of a tensor framework; evaluation plans retire their own
+ * streams in bh_eval_destroy.) */
+int bh_stream_retire(void *stream);
+/* A non-blocking stream on the current device for hosts without a HIP binding of their own, and its end:
+ * bh_stream_destroy = bh_stream_retire + hipStreamDestroy. */
+int bh_stream_create(void **stream);
+int bh_stream_destroy(void *stream);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,32 @@ def test_pool_chains_match_golden(oracle, golden_chains):
                    ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter')}, got, (name, seed))
 
 
+def test_pool_lifetime_close_and_context_manager(oracle):
+    """A pool's native resources end with close() / the with-block, not whenever the interpreter collects it;
+    its results stay readable, a closed pool refuses to run, several pools in a row are the same inversion
+    (the reference: MCMC_Optimizer.mp_inversion can be called again, src/mcmcOptimizer.py:202-283)."""
+    from bayhunter_amd._lib import BayHunterAmdError
+    case = dict(CASES['fixednoise'], burnin=30, main=20)
+    first = None
+    for k in range(3):
+        with make_pool(oracle, DATA, case, seeds=[5, 6], groups=2) as pool:
+            assert not pool.closed
+            pool.run()
+        assert pool.closed and all(g.handle is None for g in pool.groups)
+        pool.close()                                                     # idempotent
+        n = pool.counters()[0]
+        got = [pool.chain(i) for i in range(2)]
+        assert got[0]['n'] == n[0] >= 1 and pool.weighted(0)[1] is not None
+        if first is None:
+            first = got
+        for a, b in zip(first, got):
+            _same(a, b, k)
+    unrun = make_pool(oracle, DATA, case, seeds=[5])
+    unrun.close()
+    with pytest.raises(BayHunterAmdError, match='closed'):
+        unrun.run()
+
+
 def test_storage_overflow_is_reported(oracle):
     case = dict(CASES['tutorial'], burnin=30, main=10)
     case['initparams'] = dict(case['initparams'], acceptance=(1, 2))    # room for int(40*0.02) = 0 -> refuse

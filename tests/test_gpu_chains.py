@@ -279,3 +279,61 @@ def test_eval_plan_more_than_60_periods_and_swd_only():
     torch.cuda.synchronize()
     assert np.array_equal(logL, wl.cpu().numpy(), equal_nan=True) and np.array_equal(mis, wm.cpu().numpy(), equal_nan=True)
     assert np.isfinite(logL).mean() > 0.5
+
+
+def test_pools_and_plans_made_run_and_closed_back_to_back():
+    """the driver's bench died in its chain-pool leg with `hipEventQuery(queue slot):
+    operation not permitted when stream is capturing` -- work-queue slot events of the library outlived the
+    evaluation plans' streams they were recorded on.  Five pools (two plans each) made, run and closed one after
+    the other in ONE process, forward launches on other streams in between, a caller-owned stream retired and
+    destroyed, with a ring of only 8 slots so that every launch re-claims a slot an earlier pool used
+    (tests/scenarios/pool_lifecycle.py; a child process: the old failure could as well be a crash)."""
+    import json
+    import subprocess
+    env = dict(os.environ, BH_SWD_QUEUE_SLOTS='8')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'scenarios', 'pool_lifecycle.py'), '5', '600', '40'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['ok'] and rec['pools'] == 5 and rec['plans_closed'] == 10 and rec['forward_checks'] == 13 and rec['slots'] == '8'
+
+
+def test_eval_plan_context_manager_and_use_after_close():
+    from bayhunter_amd._lib import BayHunterAmdError
+    from chain_scenario import joint_target
+    joint = joint_target(DATA)
+    joint.set_target_covariance([True, True], [0.0, 0.9], 1e-5)
+    packed, nl, noise = _random_batch(40, 12, joint.ntargets, seed=4)
+    with joint.eval_plan(64, 12) as plan:
+        plan.packed[:40], plan.nlay[:40], plan.noise[:40] = packed, nl, noise
+        plan.submit(40)
+        logL = plan.wait()[0].copy()
+    assert plan.closed and plan.packed is None and np.isfinite(logL).mean() > 0.9
+    plan.close()                                           # idempotent
+    with pytest.raises(BayHunterAmdError, match='closed'):
+        plan.submit(1)
+    with pytest.raises(BayHunterAmdError, match='closed'):
+        plan.wait()
+
+
+def test_rf_only_plan_flags_bad_depths_like_the_engine():
+    """without a dispersion kernel the plan only zeroed the flags, so a model deeper than the plan
+    reached the likelihood as a NaN row with flag 0 where ForwardEngine raises BH_MODEL_BAD_DEPTH (2)."""
+    import torch
+    from bayhunter_amd import targets as T
+    x = np.linspace(-5, 35, 201)
+    joint = T.JointTarget([T.PReceiverFunction(x, np.zeros(201))])
+    joint.set_target_covariance([True], [0.0], None)
+    packed, nl, noise = _random_batch(64, 10, 1, seed=11, ragged=(2, 10))
+    nl = nl.copy()
+    nl[3], nl[17], nl[40] = 0, 11, -2                      # outside 1..Lmax
+    with joint.eval_plan(64, 10) as plan:
+        plan.packed[:], plan.nlay[:], plan.noise[:] = packed, nl, noise
+        plan.submit(64)
+        logL, mis = (a.copy() for a in plan.wait())
+    wl, wm = joint.evaluate_batch(packed[:, 0], packed[:, 1], packed[:, 2], nl, noise, RHO=packed[:, 3])
+    torch.cuda.synchronize()
+    assert np.array_equal(logL, wl.cpu().numpy(), equal_nan=True) and np.array_equal(mis, wm.cpu().numpy(), equal_nan=True)
+    bad = np.zeros(64, dtype=bool)
+    bad[[3, 17, 40]] = True
+    assert np.all(logL[bad] == -1e15) and np.all(np.isfinite(logL[~bad])) and np.all(logL[~bad] > -1e15)
