@@ -485,6 +485,15 @@ struct TeamwVals {
     {
         return ((right >> j) & 1) ? SWD_GO_RIGHT : ((left >> j) & 1) ? SWD_GO_LEFT : SWD_GO_STOP;
     }
+    // chain nodes first, first + 2, ... (at most max) in a row whose decision is `dir`: the ballots, shifted, with
+    // the chain's nodes on the even bits
+    __device__ __forceinline__ int chain_run(const SwdState &, int first, int dir, int max) const
+    {
+        const unsigned long long m = (dir == SWD_GO_RIGHT ? right : left) >> first;
+        const unsigned long long stop = ~m & 0x5555555555555555ull;
+        const int n = stop ? (__ffsll((long long)stop) - 1) >> 1 : 32;
+        return n < max ? n : max;
+    }
     __device__ __forceinline__ TeamwNode node(const SwdState &, int j) const
     {
         TeamwNode a;
@@ -667,7 +676,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     WideSrc src{A, tg, t, lane, nl, 0, b, res};
     SwdState S;
     swd_state_init(S);
-    TeamwNext nxt{-1, -1, 0.0};
+    TeamwNext nxt{-1, -1, 0.0, 0, 0, 0.0, 0.0, 0.0};
     BH_TP_DECL;
     long rounds = 0;
     bool first = true;

@@ -307,16 +307,24 @@ struct TeamwRound {
                                   //    slot 2i-1 = A_i, slot 2i = B_i, i = 1 .. nhalf/2
     int ngrp;                     // scan groups in use (0..2); g1 follows g0
     TeamwScan g0, g1;
+    int pm0, pmi, npm;            // predicted-cell midpoints of g0's scan: slots pm0 .. pm0+npm-1 hold the midpoints
+                                  // of scan cells pmi .. pmi+npm-1 (swd_teamw_predict)
 };
 #ifndef SWD_TEAMW_CHAIN_MAX
 #define SWD_TEAMW_CHAIN_MAX 14      // deepest inner chain (0.005 -> 1e-6 c takes 11-13 halvings)
 #endif
 
-// omega of the search that follows the current one, kept across the rounds of a search (k, pass)
+// What the plan keeps across the rounds of a search: omega of the search that follows the current one (k, pass),
+// and the roots of the last periods (first solves), from which the next root is extrapolated (swd_teamw_predict).
 struct TeamwNext {
     int k, pass;
     double oms;
+    int hk, nr;                   // period the history belongs to; roots held (0..3)
+    double r1, r2, r3;            // c(hk-1), c(hk-2), c(hk-3)
 };
+#ifndef SWD_TEAMW_NPM
+#define SWD_TEAMW_NPM 3           // predicted-cell midpoints per scan round (0: none)
+#endif
 
 // The number of halvings that bring a bracket of width w down to tol: the smallest i >= 0 with w / 2^i <= tol,
 // at most SWD_TEAMW_CHAIN_MAX (w, tol > 0 and finite; anything else: 0).  Powers of two scale exactly, so this is
@@ -333,6 +341,62 @@ BH_DEV int swd_halvings(double w, double tol)
 #endif
     int i = ew - et + (mw > mt ? 1 : 0);            // w = mw 2^ew, tol = mt 2^et, mantissas in [0.5, 1)
     return i < 0 ? 0 : i > SWD_TEAMW_CHAIN_MAX ? SWD_TEAMW_CHAIN_MAX : i;
+}
+
+// ---- where will this scan end?  -----------------------------------------------------------------
+// The first bisection after a bracket (`nevill`'s opening `half`, surfdisp96.f:583) is an evaluation at the
+// midpoint of the scan cell that holds the sign change, and it is alone in its round: its value decides the
+// Neville estimate that follows (replay: one round in four consumes this one value).  The midpoint is known as
+// soon as the CELL is, and dispersion curves are smooth: the root of period k extrapolated from the last three
+// roots (quadratically in the period index; linearly from two) lands within one and a half cells of the true one
+// three times in four (tools/replay_rounds.py).  A scan round therefore gives its last SWD_TEAMW_NPM slots to the
+// midpoints of the predicted cell and its neighbours; when one of them is the bracketing cell the search is past
+// the first bisection in the round in which it finds the bracket.  As everywhere in the plan a wrong prediction
+// costs lanes, never a value: slots are consumed by matching (omega, c).
+// History: called by the plan of every round; period S.k of a mode has seen the roots of S.k - 1, ... .
+BH_DEV void swd_teamw_history(const SwdState &S, TeamwNext &nx)
+{
+    if (nx.hk == S.k) return;
+    if (S.k == nx.hk + 1 && S.k > 1) {
+        nx.r3 = nx.r2; nx.r2 = nx.r1; nx.r1 = S.cprev;
+        nx.nr = nx.nr < 3 ? nx.nr + 1 : 3;
+    } else {
+        nx.nr = 0;                                  // first period of a mode (or periods skipped: no history)
+        if (S.k > 1) { nx.r1 = S.cprev; nx.nr = 1; }
+    }
+    nx.hk = S.k;
+}
+// Predicted root of the search the state is in (NaN: no prediction).
+BH_DEV double swd_teamw_predict(const SwdState &S, const SwdTargetDev &tg, const double *BH_RESTRICT per,
+                                const TeamwNext &nx)
+{
+    if (tg.mode != 1 || S.iq != 1) return __builtin_nan("");
+    if (S.pass == 1) {
+        // second solve of a group-velocity pair, at T/(1-h) instead of T/(1+h): the root moves by the curve's
+        // slope -- taken from the step since the previous period -- times the difference of the two periods
+        if (nx.nr < 1 || S.k < 2) return __builtin_nan("");
+        const double dt = (double)S.t1b - (double)S.t1a, step = per[S.k - 1] - per[S.k - 2];
+        return S.ck + (S.ck - nx.r1) * (dt / step);
+    }
+    if (nx.nr >= 3) return 3.0 * (nx.r1 - nx.r2) + nx.r3;
+    if (nx.nr == 2) return 2.0 * nx.r1 - nx.r2;
+    return __builtin_nan("");
+}
+// Gives the last slots of a scan group (stride 1, `nscan` cells from slot `scan0`, ending at slot `end`) to the
+// midpoints of the predicted cell and its neighbours; returns the group's new cell count.
+BH_DEV int swd_teamw_reserve_mids(TeamwRound &R, const TeamwScan &g, int end, double cpred)
+{
+    R.npm = 0; R.pm0 = end; R.pmi = 0;
+    const int npm = SWD_TEAMW_NPM;
+    if (npm <= 0 || g.stride != 1 || g.nscan <= npm + 1 || !(cpred == cpred)) return g.nscan;
+    const double pf = (cpred - g.base) * 200.0;     // cells of dc = 0.005 (an estimate: any rounding will do)
+    if (!(pf > -1.0 && pf < 80.0)) return g.nscan;
+    int lo = (int)pf - npm / 2;                     // first cell with a midpoint
+    if (lo < 0) lo = 0;
+    const int kept = g.nscan - npm;                 // cells the scan keeps
+    if (lo >= kept) return g.nscan;                 // the predicted cells lie beyond this round: scan on
+    R.npm = npm; R.pm0 = end - npm; R.pmi = lo;
+    return kept;
 }
 
 // lays one scan group out in slots [first, first + room): entry (if has_entry) + scan
@@ -385,6 +449,8 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
     R.nt = 1; R.nhalf = 0; R.ngrp = 0; R.chains = 0;
     R.g0.entry = -1; R.g0.scan0 = 1; R.g0.stride = 1; R.g0.nscan = 0; R.g0.base = S.ceval; R.g0.oms = S.omega;
     R.g1 = R.g0;
+    R.pm0 = 0; R.pmi = 0; R.npm = 0;
+    swd_teamw_history(S, nx);
     if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
     if (cap <= 1) return R;
     if (S.st == SWD_ST_A) {
@@ -392,6 +458,7 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
         // (swd_bracket_next resets c1 to clow when c1 + dc <= clow)
         R.ngrp = 1;
         R.nt = swd_teamw_scan_layout(R.g0, 1, cap - 1, false, R.g0.base + dc > S.clow);
+        R.g0.nscan = swd_teamw_reserve_mids(R, R.g0, R.nt, swd_teamw_predict(S, tg, per, nx));
         return R;
     }
     if (S.st == SWD_ST_B) {
@@ -400,6 +467,7 @@ BH_DEV TeamwRound swd_teamw_round(const SwdState &S, const SwdTargetDev &tg, con
         if (S.idir > 0 && S.c1 + dc == S.ceval && R.g0.base + dc > S.clow) {
             R.ngrp = 1;
             R.nt = swd_teamw_scan_layout(R.g0, 0, cap, false, true);
+            R.g0.nscan = swd_teamw_reserve_mids(R, R.g0, R.nt, swd_teamw_predict(S, tg, per, nx));
         }
         return R;
     }
@@ -541,12 +609,13 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
         *c = mid;
         return;
     }
-    const TeamwScan &g = swd_teamw_group(R, j);
+    const bool pmid = R.npm > 0 && j >= R.pm0;       // a predicted-cell midpoint of g0's scan
+    const TeamwScan &g = pmid ? R.g0 : swd_teamw_group(R, j);
     *om = g.oms;
-    if (j == g.entry) { *c = g.base; return; }
+    if (!pmid && j == g.entry) { *c = g.base; return; }
     const int q = j - g.scan0;
-    const int i = g.stride == 2 ? q >> 1 : q;        // scan cell
-    const bool mid = g.stride == 2 && (q & 1);
+    const int i = pmid ? R.pmi + (j - R.pm0) : g.stride == 2 ? q >> 1 : q;        // scan cell
+    const bool mid = pmid || (g.stride == 2 && (q & 1));
     // base_0 = base, base_{n+1} = c_n = base_n + dc by repeated addition.  The scan stops at the first
     // base outside [cc, cfail) (swd_control: "c1 < cm or c1 >= betmx + dc -> no root"); the bases
     // increase, so it is enough to look at the first and at this cell's
@@ -711,6 +780,8 @@ BH_DEV double swd_teamw_chain_one(const Lay &lay, int ifunc, const SwdState &S, 
 //          bit `neg`;
 //          `int go(const SwdState &, int j)`, `TeamwNode node(const SwdState &, int j)`: swd_teamw_node
 //          of tree node j for the state the round was planned with;
+//          `int chain_run(const SwdState &, int first, int dir, int max)`: how many of the chain nodes first,
+//          first + 2, ... (at most max) in a row decide `dir`;
 //          `probe(int)`, `count(int, int)`: cycle probes of the diagnostic build, else empty.
 // Scan trials without a sign change are the bulk of all evaluations (two thirds) and
 // each costs a pass through swd_control although all it does is "c1 = c2, del1 = del2, next grid
@@ -741,10 +812,15 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
                 if (g0 != SWD_GO_STOP) {
                     const int inner = g0 == SWD_GO_LEFT ? SWD_GO_RIGHT : SWD_GO_LEFT;
                     last = g0 == SWD_GO_LEFT ? 1 : 2;
-                    lev = 1;
-                    while (last + 2 <= R.nhalf && vals.go(S, last) == inner) { last += 2; lev++; }
+                    // nodes last, last + 2, ... of the chain, as long as each sends the search on inwards
+                    const int steps = vals.chain_run(S, last, inner, (R.nhalf - last) >> 1);
+                    last += 2 * steps;
+                    lev = 1 + steps;
                 }
             } else {
+#if !defined(BH_HOSTSIM)
+#pragma clang loop unroll(disable)
+#endif
                 while (2 * last + 2 <= R.nhalf) {                     // `last` has children in the tree
                     const int go = vals.go(S, last);
                     if (go == SWD_GO_STOP) break;

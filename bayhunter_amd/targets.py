@@ -102,11 +102,25 @@ class Valuation(object):
         return c_inv, (2 * size) * np.log(sigma) + (size - 1) * np.log(1 - corr**2)
 
     def init_covariance_gauss(self, corr, size, rcond=None):
-        lag = np.abs(np.subtract.outer(np.arange(size), np.arange(size))).astype(float)
-        rmatrix = corr**(lag**2)
-        self.corr_inv = np.linalg.pinv(rmatrix, rcond=rcond) if rcond is not None \
-            else np.linalg.inv(rmatrix)
-        self.logcorr_det = np.linalg.slogdet(rmatrix)[1]
+        # The factorisation depends on (corr, size, rcond) only and is kept: every ChainPool of a process comes
+        # through here.  Not just for the milliseconds -- numpy's OpenBLAS hands the 201 x 201 SVD to a pool of one
+        # thread per core (64 on a GPU box) whose idle workers SPIN for about a tenth of a second afterwards: 6
+        # CPU-seconds that a sampler started right behind the set-up pays for with a stall of 50-80 ms when the
+        # box's CPU quota (16 cores per 100 ms) runs out (tools/host_phase_probe.py: cgroup nr_throttled; 1 024
+        # chains 8.5e5 -> 1.29e6 chain iterations/s without the spin).  The calls themselves stay as the reference
+        # makes them (src/Targets.py:140-150): with rcond near the small singular values the pseudo-inverse, and
+        # with it the likelihood, depends on how the BLAS splits its work -- a single-threaded call gives
+        # logL = 2838.56 where the reference, and the golden vectors, have 2835.83.
+        key = (float(corr), int(size), None if rcond is None else float(rcond))
+        hit = _GAUSS_COVARIANCE.get(key)
+        if hit is None:
+            lag = np.abs(np.subtract.outer(np.arange(size), np.arange(size))).astype(float)
+            rmatrix = corr**(lag**2)
+            corr_inv = np.linalg.pinv(rmatrix, rcond=rcond) if rcond is not None else np.linalg.inv(rmatrix)
+            hit = _GAUSS_COVARIANCE[key] = (corr_inv, np.linalg.slogdet(rmatrix)[1])
+            if len(_GAUSS_COVARIANCE) > 32:
+                _GAUSS_COVARIANCE.pop(next(iter(_GAUSS_COVARIANCE)))
+        self.corr_inv, self.logcorr_det = hit[0].copy(), hit[1]
 
     def get_covariance_gauss(self, sigma, size, yerr=None, corr=None):
         return self.corr_inv / (sigma**2), (2 * size) * np.log(sigma) + self.logcorr_det
@@ -116,6 +130,10 @@ class Valuation(object):
         ydiff = ymod - yobs
         madist = ydiff.dot(c_inv).dot(ydiff)
         return -0.5 * (yobs.size * LOG_2PI + logc_det) - madist / 2.
+
+
+# (corr, size, rcond) -> (corr_inv, logcorr_det): see Valuation.init_covariance_gauss
+_GAUSS_COVARIANCE = {}
 
 
 class SingleTarget(object):

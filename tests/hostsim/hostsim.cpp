@@ -131,6 +131,12 @@ struct ArrayVals {
     void count(int, int) const {}
     int go(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, *R, *this, j).go; }
     bh::TeamwNode node(const bh::SwdState &S, int j) const { return bh::swd_teamw_node(S, *R, *this, j); }
+    int chain_run(const bh::SwdState &S, int first, int dir, int max) const
+    {
+        int n = 0;
+        while (n < max && go(S, first + 2 * n) == dir) n++;
+        return n;
+    }
     int run(int first, int stride, int count, bool neg) const
     {
         int m = 0;
@@ -159,7 +165,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
     bh::swd_state_init(S);
     double nx[12], ny[12];
     bh::NevMem nv{nx, ny};
-    bh::TeamwNext nxt{-1, -1, 0.0};
+    bh::TeamwNext nxt{-1, -1, 0.0, 0, 0, 0.0, 0.0, 0.0};
     bh::swd_nev_init(nv);
     long nc = 0, ns = 0, nr = 0;
     for (;;) {

@@ -24,6 +24,10 @@ def test_swd_and_rf_kernels_fit_one_simd_together():
     assert all(v['scratch'] == 0 for v in r.values()), r          # nothing spills to memory
     assert _alloc(r['swd_kernel']['vgpr']) <= 192 and _alloc(r['rf_kernel<false>']['vgpr']) <= 128, r
     assert 2 * _alloc(r['swd_kernel']['vgpr']) + _alloc(r['rf_kernel<false>']['vgpr']) <= 512
+    # a multi-target call that is latency-bound on the lane kernel moves its heaviest target to 128-lane teams beside it
+    # (capi.hip: plan_forms; BASELINE cfg3: 22.7 -> 17 ms): one lane-kernel wave and two team waves share a SIMD.
+    # (Ten more registers in the wide teams -- a Neville table in register lanes, round 4 -- and cfg3 took 28.7 ms.)
+    assert _alloc(r['swd_kernel']['vgpr']) + 2 * _alloc(r['swd_team128_kernel']['vgpr']) <= 512, r
     # the team forms keep two (narrow teams) / three (wide teams) waves per SIMD
     for k, v in r.items():
         if k.startswith('swd_team'):

@@ -28,17 +28,19 @@ def main():
         iters = int(os.environ.get('CHAIN_BENCH_ITERS', 120 if n <= 4096 else 60))
         # a short pool of the same size first: first-use costs (kernel forms loaded on their first launch, helper
         # threads, pinned buffers) are not chain iterations
-        ChainPool(joint_target(data), initparams=dict(case['initparams'], iter_burnin=6, iter_main=2, acceptance=(40, 100)),
-                  modelpriors=case['priors'], seeds=np.arange(n) % 1000, nmodels=9).run()
+        with ChainPool(joint_target(data), initparams=dict(case['initparams'], iter_burnin=6, iter_main=2, acceptance=(40, 100)),
+                       modelpriors=case['priors'], seeds=np.arange(n) % 1000, nmodels=9) as warm:
+            warm.run()
+        time.sleep(0.25)          # numpy's OpenBLAS workers spin ~0.1 s after the set-up's factorisation (bench.py: BLAS_SETTLE_S)
         joint = joint_target(data)
         ip = dict(case['initparams'], iter_burnin=iters, iter_main=iters // 2, acceptance=(40, 100))
-        pool = ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=np.arange(n) % 1000,
-                         evaluator=GpuEvaluator(joint),
-                         groups=int(os.environ['CHAIN_BENCH_GROUPS']) if 'CHAIN_BENCH_GROUPS' in os.environ else None)
-        t0 = time.perf_counter()
-        pool.run()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        with ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=np.arange(n) % 1000,
+                       evaluator=GpuEvaluator(joint),
+                       groups=int(os.environ['CHAIN_BENCH_GROUPS']) if 'CHAIN_BENCH_GROUPS' in os.environ else None) as pool:
+            t0 = time.perf_counter()
+            pool.run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
         total = n * (iters + iters // 2)
         acc = pool.counters()[0]
         print(json.dumps(dict(nchains=n, iterations=iters + iters // 2, seconds=round(dt, 3),

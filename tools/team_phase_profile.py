@@ -22,6 +22,7 @@ from bayhunter_amd import _lib  # noqa: E402
 def profile_library():
     """The -DBH_TEAM_PROFILE build, keyed by the source hash: tools/_prof/ (git-ignored, travels to the GPU
     box: `python tools/team_phase_profile.py --build-only` here saves a minute of box time) or gpurun_out/."""
+    extra = os.environ.get('BH_EXTRA_HIPCC_FLAGS', '').split()
     name = 'libbayhunter_amd_teamprof_%s.so' % _lib.source_hash()
     pre = os.path.join(ROOT, 'tools', '_prof', name)
     if os.path.exists(pre):
@@ -30,7 +31,7 @@ def profile_library():
     os.makedirs(d, exist_ok=True)
     so = os.path.join(d, name)
     if not os.path.exists(so):
-        subprocess.run(['/opt/rocm/bin/hipcc'] + _lib.HIPCC_FLAGS + ['-DBH_TEAM_PROFILE'] + _lib.SOURCES + ['-o', so],
+        subprocess.run(['/opt/rocm/bin/hipcc'] + _lib.HIPCC_FLAGS + extra + ['-DBH_TEAM_PROFILE'] + _lib.SOURCES + ['-o', so],
                        cwd=_lib.CSRC, check=True)
     return so
 
