@@ -498,8 +498,10 @@ struct TeamwVals {
     {
         TeamwNode a;
         a.go = SWD_GO_STOP;
+        a.out = __builtin_amdgcn_readlane(nd.out, j);
         a.c1 = readlane_d(nd.c1, j); a.d1 = readlane_d(nd.d1, j);
         a.c2 = readlane_d(nd.c2, j); a.d2 = readlane_d(nd.d2, j);
+        a.c3n = readlane_d(nd.c3n, j);
         return a;
     }
     // slots first, first + stride, ... (at most count) in a row that are valid and whose value has sign
@@ -776,7 +778,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             // refinement round: lane j evaluates node j of the bisection tree (what the search does when
             // it arrives there), the consuming loop then follows the decisions
             TeamwNode nd;
-            nd.go = SWD_GO_STOP; nd.c1 = nd.d1 = nd.c2 = nd.d2 = 0.0;
+            nd.go = SWD_GO_STOP; nd.out = SWD_OUT_CONTROL; nd.c1 = nd.d1 = nd.c2 = nd.d2 = nd.c3n = 0.0;
             unsigned long long goL = 0, goR = 0;
             if (R.nhalf > 0) {
                 const bool innode = wl <= R.nhalf;

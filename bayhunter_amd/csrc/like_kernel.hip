@@ -351,17 +351,38 @@ hipError_t launch_division_selftest(long n, unsigned seed, int max_exp, unsigned
 //                of vs at that period (weights exp(-z/reach) h, reach = 0.35 * 3.5 km/s * period; the
 //                half-space counts with a thickness of one reach) minus 0.79 min(vs), classes of 0.15
 //   bits  0..17  S-wave travel time through the stack in 1/256 s: neighbours in a wave should be alike
+// Loads: a wave stages the h and vs rows of its 64 models in LDS with lane-consecutive addresses (the rows of a
+// model are Lmax doubles long and mstride apart: per-thread loads of one model's row each fetched a 64-byte sector
+// for every 8 bytes used -- 1.18 GB for the 84 MB of layer values of 524 288 ten-layer models, round 3).
 __global__ void order_key_kernel(int B, int Lmax, int mstride, const int *nlay, const double *h,
                                  const double *vs, float reach, int by_length, int *keys)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    extern __shared__ float okl[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Lp = Lmax | 1;                                // odd row pitch: thread m reads row m without bank conflicts
+    float *hl = okl + (long)wave * 2 * 64 * Lp, *vl = hl + 64 * Lp;
+    const long b0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
+    const int nm = b0 >= B ? 0 : (int)(B - b0 < 64 ? B - b0 : 64);
+    {
+        int m = lane / Lmax, i = lane - m * Lmax;           // element e = lane + 64 k of the [64][Lmax] tile
+        const int dm = 64 / Lmax, di = 64 - dm * Lmax;
+        while (m < nm) {
+            const long g = (b0 + m) * (long)mstride + i;
+            hl[m * Lp + i] = (float)h[g];
+            vl[m * Lp + i] = (float)vs[g];
+            m += dm; i += di;
+            if (i >= Lmax) { i -= Lmax; m++; }
+        }
+    }
+    __syncthreads();                                        // (a wave reads only what it wrote itself)
+    const long b = b0 + lane;
+    if (lane >= nm) return;
     int nl = nlay[b];
     nl = nl < 1 ? 1 : (nl > Lmax ? Lmax : nl);
-    const double *hb = h + (long)b * mstride, *vb = vs + (long)b * mstride;
+    const float *hb = hl + lane * Lp, *vb = vl + lane * Lp;
     float tt = 0.f, z = 0.f, sw = 0.f, svw = 0.f, vmin = 1e9f;
     for (int i = 0; i < nl; i++) {
-        const float hi = (float)hb[i], vi = (float)vb[i];
+        const float hi = hb[i], vi = vb[i];
         if (!(vi > 0.f)) { z += hi; continue; }           // water layer: no S wave
         tt += hi / vi;
         const bool hs = i == nl - 1;
@@ -384,8 +405,13 @@ __global__ void order_key_kernel(int B, int Lmax, int mstride, const int *nlay, 
 hipError_t launch_order_keys(int B, int Lmax, int mstride, const int *nlay, const double *h, const double *vs,
                              double reach, int by_length, int *keys, hipStream_t stream)
 {
-    hipLaunchKernelGGL(order_key_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, B, Lmax, mstride, nlay, h, vs,
-                       (float)reach, by_length, keys);
+    // waves per workgroup: as many as 64 KiB of LDS hold (2 x 64 x (Lmax | 1) floats each), at most four
+    const size_t per_wave = (size_t)2 * 64 * (Lmax | 1) * sizeof(float);
+    int W = (int)((64 * 1024) / per_wave);
+    W = W < 1 ? 1 : W > 4 ? 4 : W;
+    const long waves = ((long)B + 63) / 64;
+    hipLaunchKernelGGL(order_key_kernel, dim3((unsigned)((waves + W - 1) / W)), dim3(64 * W), per_wave * W, stream, B, Lmax,
+                       mstride, nlay, h, vs, (float)reach, by_length, keys);
     return hipGetLastError();
 }
 

@@ -505,6 +505,17 @@ BH_DEV bool swd_neville(NevMem &n, int &m, bool nev2, double c1, double del1, do
     return true;
 }
 
+// The table a Neville step from the bracket ends leaves behind (swd_neville with nev2 = false): x(1) = the new
+// estimate -- or c1 when the step failed its guard --, y(1) = del1, x(2) = c2, y(2) = del2.
+BH_DEV void swd_nev_restart(NevMem &n, double x1, double del1, double c2, double del2)
+{
+    n.x[1] = x1; n.y[1] = del1; n.x[2] = c2; n.y[2] = del2;
+}
+BH_DEV void swd_nev_restart(NevRegs &n, double x1, double del1, double c2, double del2)
+{
+    n.x1 = x1; n.y1 = del1; n.x2 = c2; n.y2 = del2;
+}
+
 BH_DEV void swd_put_direct(SwdState &S, int k, int kmax, float v) { swd_put(S.out, k, kmax, v, S.pend); }
 BH_DEV void swd_zero_direct(SwdState &S, int k, int kmax)
 {

@@ -634,9 +634,20 @@ BH_DEV void swd_teamw_trial(const TeamwRound &R, const SwdState &S, int j, doubl
 // consuming loop follows the decisions down the tree instead of passing through swd_control once per
 // level.  `del(slot)` returns the period-equation value of a slot.
 enum { SWD_GO_LEFT = 0, SWD_GO_RIGHT = 1, SWD_GO_STOP = 2 };    // LEFT: c2 = c3 (child 2j+1), RIGHT: c1 = c3
+// `out` says what swd_control does when it is handed the node's value after an arrival by bisection (j > 0) -- the
+// lane of node j works that out too, for all nodes at once, so that the consuming loop can take the LAST node of a
+// walk without a swd_control call (130 mostly scalar instructions on the control wave, 1.3 of them per round):
+//   0  not worked out (node 0: its Neville table may hold more than the bracket ends): c1 .. d2 are the bracket
+//      on ARRIVAL, swd_control takes the value
+//   1  the root is found (surfdisp96.f:614)           c1 .. d2: the bracket AFTER the update (:605-612)
+//   2  a bisection follows (:620-640, 661)            c3n = its point
+//   3  a Neville step follows: from a fresh table of the two bracket ends it is the secant (:642-658), c3n
+//   4  that step failed its guard (:651): the table is restarted all the same, a bisection follows at c3n
+enum { SWD_OUT_CONTROL = 0, SWD_OUT_FINISH = 1, SWD_OUT_HALF = 2, SWD_OUT_NEVILLE = 3, SWD_OUT_NEVILLE_BAD = 4 };
 struct TeamwNode {
-    int go;
-    double c1, d1, c2, d2;        // the bracket the search has when it arrives at the node
+    int go, out;
+    double c1, d1, c2, d2;
+    double c3n;
 };
 // slot the search was at before it arrived at node j (> 0)
 BH_DEV int swd_teamw_parent(const TeamwRound &R, int j)
@@ -695,8 +706,21 @@ BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const TeamwRound &R, const V 
     if (fabs(c1 - c2) <= 1.e-6 * c1) stop = true;
     if (bh_signs_differ(s13, s32)) nev = 0;
     const double ss1 = fabs(d1), s1 = pct * ss1, ss2 = fabs(d2), s2 = pct * ss2;
-    if (!(s1 > ss2 || s2 > ss1 || nev == 0)) stop = true;       // a Neville step comes next
+    const bool do_half = s1 > ss2 || s2 > ss1 || nev == 0;
+    const bool fin = stop;
+    if (!do_half) stop = true;                                  // a Neville step comes next
     n.go = stop ? SWD_GO_STOP : neg ? SWD_GO_LEFT : SWD_GO_RIGHT;
+    n.out = SWD_OUT_CONTROL;
+    n.c3n = 0.0;
+    if (j > 0) {
+        // swd_neville with nev != 2: x(1), y(1) = c1, del1; x(2), y(2) = c2, del2; one step
+        const double denom = d2 - d1, guard = 1.0e-10 * fabs(d2);
+        const bool bad = fabs(denom) < guard;
+        const double sec = (-d1 * c2 + d2 * c1) / denom, half = 0.5 * (c1 + c2);
+        n.out = fin ? SWD_OUT_FINISH : do_half ? SWD_OUT_HALF : bad ? SWD_OUT_NEVILLE_BAD : SWD_OUT_NEVILLE;
+        n.c3n = (n.out == SWD_OUT_NEVILLE) ? sec : half;
+        n.c1 = c1; n.d1 = d1; n.c2 = c2; n.d2 = d2;
+    }
     return n;
 }
 
@@ -804,6 +828,7 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
         int j = used == 0 ? 0 : vals.find(S.omega, S.ceval);
         vals.probe(4);
         if (j < 0) break;
+        bool handled = false;
         if (tree && used == 0 && R.nhalf > 0 && S.nctrl < 80) {       // (refinement round: ST_TOP / ST_MID)
             int last = 0, lev = 0;
             if (R.chains) {
@@ -829,20 +854,34 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
                 }
             }
             if (lev > 0) {
+                // (`last` > 0: the lane of that node has worked out what swd_control does with its value)
                 const TeamwNode a = vals.node(S, last);
-                S.nctrl += lev - (S.st == SWD_ST_MID ? 1 : 0);        // (ST_MID does not count its step)
+                S.nctrl += lev + 1 - (S.st == SWD_ST_MID ? 1 : 0);    // (ST_MID does not count its step)
                 S.c1 = a.c1; S.del1 = a.d1; S.c2 = a.c2; S.del2 = a.d2;
-                S.del3 = vals.del(swd_teamw_parent(R, last));
+                S.del3 = vals.del(last);
                 S.c3 = vals.c(last);
-                S.ceval = S.c3;
                 S.nev = 1; S.m = 1; S.st = SWD_ST_TOP;
-                used = lev;
-                j = last;
+                if (a.out == SWD_OUT_FINISH) {                        // label 1000 of nevill + getsol's tail
+                    S.ceval = S.c3;
+                    S.c1 = S.c3;
+                    S.ev = (S.c1 > (double)S.betmx) ? SWD_EV_NOROOT : SWD_EV_SOLVED;
+                } else {
+                    if (a.out != SWD_OUT_HALF) {                      // the table the Neville step leaves behind
+                        const bool ok = a.out == SWD_OUT_NEVILLE;
+                        swd_nev_restart(nv, ok ? a.c3n : a.c1, a.d1, a.c2, a.d2);
+                        if (ok) { S.nev = 2; S.m = 2; }
+                    }
+                    S.c3 = a.c3n;
+                    S.ceval = S.c3;
+                }
+                used = lev + 1;
+                handled = true;
                 vals.count(12, lev);
+                vals.count(11, 1);
             }
             vals.probe(15);
         }
-        if (S.st == SWD_ST_B && S.idir > 0 && R.ngrp > 0 && (R.nhalf == 0 || j > R.nhalf)) {
+        if (!handled && S.st == SWD_ST_B && S.idir > 0 && R.ngrp > 0 && (R.nhalf == 0 || j > R.nhalf)) {
             const TeamwScan &g = swd_teamw_group(R, j);
             const int q = j - g.scan0, i = q / g.stride;
             if (q >= 0 && q == i * g.stride && i < g.nscan) {
@@ -859,23 +898,25 @@ BH_DEV int swd_teamw_consume(SwdState &S, Nev &nv, Lay &lay, Src &src, const Swd
                     if (S.c1 < S.cc || S.c1 >= S.cfail) {
                         S.nbrk += m - 1;
                         S.ev = SWD_EV_NOROOT;
-                        swd_events(S, lay, src, tg, per, wss, false);
-                        if (S.st == SWD_ST_DONE) break;
                     } else {
                         S.nbrk += m;
                         S.c2 = swd_bracket_next(S.c1, S.idir, S.clow, dc);
                         S.ceval = S.c2;
                     }
+                    handled = true;
                     vals.probe(5);
                     vals.count(10, 1);
-                    continue;
                 }
             }
         }
-        swd_control(S, vals.del(j), nv);
-        used++;
-        vals.probe(6);
-        vals.count(11, 1);
+        if (!handled) {
+            swd_control(S, vals.del(j), nv);
+            used++;
+            vals.probe(6);
+            vals.count(11, 1);
+        }
+        // the one place of the loop where a pending event is taken (root found / no root: results stored, next
+        // period or second solve set up) -- three inlined copies of the driver were 1 200 instructions of code
         if (S.ev != SWD_EV_NONE) {
             swd_events(S, lay, src, tg, per, wss, false);
             vals.probe(7);

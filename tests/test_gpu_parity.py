@@ -768,3 +768,52 @@ def test_nan_models_end_in_every_kernel_form(lib, kernel):
     assert np.all(err[4] == 1) and np.all(out[4] == 0.0)          # all-NaN model: the step cap ends the scan
     ok = [0, 1, 3, 5]
     assert np.array_equal(out[ok], ref[ok]) and np.array_equal(err[ok], rerr[ok])
+
+
+@pytest.mark.parametrize('Lmax,B,packed', [(5, 1000, True), (10, 4099, True), (31, 700, False), (100, 130, True), (2, 65, False)])
+def test_order_keys_staged_through_lds_equal_the_per_model_formula(lib, Lmax, B, packed):
+    """The processing-order keys (like_kernel.hip: order_key_kernel; a wave stages the rows of its 64 models in LDS
+    with coalesced loads since round 4) against the formula evaluated per model in numpy: depth field exact, travel
+    time to one unit of 1/256 s, length class to one class (the device uses its fast exponential) -- for packed and
+    separate arrays, row lengths that divide 64 and that do not, more layers than lanes, ragged and partial tiles."""
+    import ctypes as C
+    import torch
+    from bayhunter_amd import _lib
+    kw = dict(zmax=600.0, thickmin=0.01) if Lmax > 40 else {}
+    H, VP, VS, RHO, nl = draw_models(B, (1, Lmax) if Lmax > 2 else 2, seed=90 + Lmax, sorted_vs=False, Lmax=Lmax, **kw)
+    VS = VS.copy()
+    VS[::7, 0] = 0.0                                                     # some water-covered models
+    dev = torch.device('cuda')
+    if packed:
+        blk = torch.from_numpy(np.ascontiguousarray(np.stack([H, VP, VS, RHO], axis=1))).to(dev)
+        hp, vp_, stride = blk[:, 0, :].data_ptr(), blk[:, 2, :].data_ptr(), 4 * Lmax
+    else:
+        th, tv = torch.from_numpy(np.ascontiguousarray(H)).to(dev), torch.from_numpy(np.ascontiguousarray(VS)).to(dev)
+        hp, vp_, stride = th.data_ptr(), tv.data_ptr(), Lmax
+    tn = torch.from_numpy(nl.astype(np.int32)).to(dev)
+    keys = torch.empty(B, dtype=torch.int32, device=dev)
+    tmax = 41.0
+    _lib.check(lib.bh_swd_order_keys(B, Lmax, stride, tn.data_ptr(), hp, vp_, tmax, 1, keys.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = keys.cpu().numpy()
+    f = np.float32
+    reach = f(0.35 * 3.5 * tmax)
+    for b in range(B):
+        n = int(nl[b])
+        tt = z = sw = svw = f(0)
+        vmin = f(1e9)
+        for i in range(n):
+            hi, vi = f(H[b, i]), f(VS[b, i])
+            if not vi > 0:
+                z = f(z + hi)
+                continue
+            tt = f(tt + hi / vi)
+            hs = i == n - 1
+            zmid = f(z + f(10)) if hs else f(z + f(0.5) * hi)
+            w = f(np.exp(-zmid / reach) * (reach if hs else hi))
+            sw, svw, vmin, z = f(sw + w), f(svw + vi * w), min(vmin, vi), f(z + hi)
+        cls = int(min(max(np.floor((f(6.0) - (f(0.92) * svw / sw - f(0.79) * vmin)) / f(0.15)), 0), 63)) if sw > 0 else 0
+        t18 = int(min(max(tt * f(256), 0), 262143))
+        k = int(got[b])
+        assert k >> 24 == 127 - n, (b, n)
+        assert abs(((k >> 18) & 63) - cls) <= 1 and abs((k & 0x3ffff) - t18) <= 1, (b, k, cls, t18)
