@@ -5,7 +5,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
  *
  * Pinned against (a) the reference's own native sources compiled into oracle/_ref/ in the
- * development container (bit-identical, see tests/test_oracle_vs_ref.py and
+ * development container (bit-identical, see tests/test_oracle.py::test_live_against_reference and
  * tests/golden/make_golden.py) and (b) the reference's shipped tutorial data
  * (tests/golden/tutorial_observed/, 4-decimal files).
  *

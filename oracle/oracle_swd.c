@@ -5,7 +5,7 @@
  * surfdisp96.f routine by routine; every function names the lines it restates.  The mixed
  * real*4 / real*8 choreography of the Fortran (implicit typing!) is replayed exactly so that the
  * output is bit-identical to the flang/gfortran-compiled reference on x86-64 without FMA
- * (checked by tests/test_oracle_vs_ref.py against oracle/_ref/libsurfdisp96_ref.so).
+ * (checked by tests/test_oracle.py::test_live_against_reference against oracle/_ref/libsurfdisp96_ref.so).
  *
  * Pinning: bit-identical to oracle/_ref on the seeded model sets of tests/golden/make_golden.py;
  * reproduces tutorial/observed/st3_{r,l}disp{ph,gr}.dat to the files' 4-decimal rounding.

@@ -8,7 +8,7 @@ Two back ends with the same call signatures:
                the restatement, to generate tests/golden/*.npz, and -- when present -- as the
                ``cpu_baseline.kind == "reference"`` leg of bench.py.
 
-Nothing under bayhunter_amd/ may import this module (checked by tests/test_layout.py).
+Nothing under bayhunter_amd/ may import this module (checked by tests/test_capi_host.py::test_product_never_touches_oracle).
 """
 import ctypes as C
 import os

@@ -181,7 +181,7 @@ def test_form_plan_moves_the_heaviest_target_of_a_latency_bound_call():
     cfg3 = [(2, 0, 40), (2, 1, 40), (1, 0, 40), (1, 1, 40)]
     assert plan(8192, 10, cfg3) == [0, 128, 0, 0] and plan(8192, 5, cfg3) == [0, 8, 0, 0]
     assert plan(64, 10, cfg3) == [512] * 4 and plan(524288, 10, cfg3) == [0] * 4
-    assert plan(8192, 10, [(2, 0, 21)]) == [64] and plan(524288, 10, [(2, 0, 21)]) == [0]
+    assert plan(12288, 10, [(2, 0, 21)]) == [64] and plan(524288, 10, [(2, 0, 21)]) == [0]
     for B in (1, 64, 1024, 8192, 65536):
         for L in (3, 10, 30):
             f = plan(B, L, cfg3)

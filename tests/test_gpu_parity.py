@@ -817,3 +817,28 @@ def test_order_keys_staged_through_lds_equal_the_per_model_formula(lib, Lmax, B,
         k = int(got[b])
         assert k >> 24 == 127 - n, (b, n)
         assert abs(((k >> 18) & 63) - cls) <= 1 and abs((k & 0x3ffff) - t18) <= 1, (b, k, cls, t18)
+
+
+def test_frequency_table_cache_is_bounded(lib):
+    """the per-(nsamp, fsamp, gauss, tshift) tables of the receiver-function kernel were cached for the
+    life of the process -- a caller of the single-model drop-in that varies the Gauss width or the time shift per call
+    grew the cache without bound.  It is a least-recently-used cache of 64 tables now; an evicted parameter set is
+    rebuilt on its next use and gives the same trace."""
+    from bayhunter_amd import _lib
+    H, VP, VS, RHO, nl = draw_models(1, 5, seed=23)
+    n = int(nl[0])
+    z = np.ascontiguousarray(np.concatenate(([0], np.cumsum(H[0, :n])[:-1])))
+    vp, vs, rh = (np.ascontiguousarray(a[0, :n]) for a in (VP, VS, RHO))
+    qp, qs = np.full(n, 450.), np.full(n, 200.)
+
+    def trace(gauss, tshift):
+        rf = np.zeros(64)
+        _lib.check(lib.bh_synrf(64, 5.0, tshift, 6.4, gauss, -1.0, float('nan'), 0, n, z.ctypes.data, vp.ctypes.data,
+                                vs.ctypes.data, rh.ctypes.data, qp.ctypes.data, qs.ctypes.data, None, None, rf.ctypes.data))
+        return rf
+    first = trace(0.8, 5.0)
+    for k in range(150):
+        trace(0.8 + 0.001 * (k + 1), 5.0 + 0.01 * k)
+    assert 1 <= lib.bh_rf_cached_tables() <= 64
+    again = trace(0.8, 5.0)                               # long evicted: rebuilt
+    assert np.array_equal(first, again) and np.isfinite(first).all() and lib.bh_rf_cached_tables() <= 64
