@@ -1,5 +1,6 @@
 // capi.hip -- the C ABI of libbayhunter_amd.so (include/bayhunter_amd.h).  Host code only.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -763,9 +764,10 @@ int bh_voronoi_to_layers(int B, int Lmax, const int *nlay, const double *vs_nucl
 size_t bh_likelihood_workspace_bytes(int B, int ntargets, const bh_like_target *targets)
 {
     if (!targets || B <= 0) return 0;
+    int groups = 0;                         // [ntargets][B][groups][2]: kernels.h, LikeArgs::gq
     for (int t = 0; t < ntargets; t++)
-        if (targets[t].cov == BH_COV_GAUSS) return (size_t)ntargets * (size_t)B * 2 * sizeof(double);
-    return 0;
+        if (targets[t].cov == BH_COV_GAUSS && targets[t].n > 0) groups = std::max(groups, bh::gq_groups_of(targets[t].n));
+    return (size_t)ntargets * (size_t)B * 2 * (size_t)groups * sizeof(double);
 }
 
 int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, const double *out,
@@ -797,6 +799,7 @@ int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, cons
     A.logL = logL; A.misfits = misfits;
     size_t need = bh_likelihood_workspace_bytes(B, ntargets, targets);
     A.gq = (need > 0 && workspace && workspace_bytes >= need) ? (double *)workspace : nullptr;
+    A.gq_groups = (int)(need / ((size_t)ntargets * (size_t)B * 2 * sizeof(double)));
     BH_HIP(bh::launch_like(A, nmax, (hipStream_t)stream));
     return BH_OK;
 }

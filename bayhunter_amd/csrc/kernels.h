@@ -80,9 +80,13 @@ struct LikeArgs {
     const int *err;
     const double *yobs, *noise, *aux;
     double *logL, *misfits;
-    double *gq;              // [ntargets][B][2] (q, sum d^2) of dense-Gaussian targets, or null
+    double *gq;              // [ntargets][B][gq_groups][2] partial (q, sum d^2) of dense-Gaussian targets, or null
+    int gq_groups;           // column-tile groups per model in gq (the widest Gaussian target's)
     LikeTargetDev tg[BH_NT];
 };
+// The dense Gaussian product runs per group of GQ_NTG column tiles of 16 (like_kernel.hip: gauss_q_kernel)
+constexpr int GQ_NTG = 4;
+__host__ __device__ inline int gq_groups_of(int n) { return ((n + 15) / 16 + GQ_NTG - 1) / GQ_NTG; }
 
 hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream);
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream);

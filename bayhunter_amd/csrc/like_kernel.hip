@@ -10,6 +10,7 @@
 // One workgroup = LIKE_M models, LIKE_T threads.  HBM traffic: the model's output row is read once
 // (it is what swd_kernel/rf_kernel just wrote), 8*(ntargets+2) bytes are written per model.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace bh {
@@ -28,20 +29,29 @@ __device__ __forceinline__ double wave_sum(double v)
 // k = l>>4), B = R^-1[4 k][16 cols] (lane l: k = l>>4, col = l&15), C/D: col = l&15,
 // row = (l>>4) + 4*reg.  All ceil(n/16) column tiles are accumulated per k-step, so every
 // residual fragment is loaded once; R^-1 (323 KB at n = 201) streams from L2.
-// Writes q and sum(d^2) per model into `gq` [B][2]; like_kernel picks them up.
+// Writes partial q and sum(d^2) per (model, column-tile group) into `gq`; like_kernel adds them up.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// One workgroup = 4 waves = 64 models (16 per wave).  R^-1 is streamed through LDS in chunks of
-// GQ_KC rows that the four waves share (round 1 had every wave fetch its own fragments from L2 with
-// 256 VGPRs and one wave per SIMD: latency-bound at 13 TFLOP/s); the next chunk is loaded into the
-// other buffer while the MFMAs of the current one issue.  NT column tiles per pass (NT*8
-// accumulator VGPRs); wider targets take several passes.
+// One workgroup = 4 waves = 64 models (16 per wave).  R^-1 is streamed through LDS in chunks of GQ_KC rows that
+// the four waves share (round 1 had every wave fetch its own fragments from L2 with 256 VGPRs and one wave per
+// SIMD: latency-bound at 13 TFLOP/s); the next chunk is loaded into the other buffer while the MFMAs of the
+// current one issue.
+// The column tiles of a target form GROUPS of GQ_NTG; every (model, group) gets its partial q and sum(d^2) in
+// `gq`, and like_kernel adds the partials in group order.  Two decompositions compute the very same partials:
+//   SPLIT   a workgroup takes ONE group (blockIdx.y) -- small batches.  Until round 4 one workgroup took all 13
+//           tiles of a 201-point receiver function, 64 models at a time: a sampler's batch of 2 048 proposals was
+//           32 workgroups on 256 CUs, each streaming the whole 323 KB matrix, on the critical path of every batch
+//           (0.074 -> 0.036 ms alone, 0.24 ms beside the other chain group's dispersion searches)
+//   fused   a workgroup takes NT tiles per pass (all 13 of a receiver function: residual fragments are loaded once
+//           per model instead of once per group) -- large batches (131 072 models: 0.58 against 0.84 ms)
+// so a model's likelihood does not depend on the size of the batch it is in.
 enum { GQ_KC = 16, GQ_WAVES = 4 };
-template <int NT>
+template <int NT, bool SPLIT>
 __global__ __launch_bounds__(64 * GQ_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void gauss_q_kernel(LikeArgs A, int t, double *gq)
 {
     extern __shared__ double rbuf[];                  // [2][GQ_KC][NT*16]
     constexpr int NP = NT * 16;
+    constexpr int NG = (NT + GQ_NTG - 1) / GQ_NTG;    // groups per pass
     const LikeTargetDev tg = A.tg[t];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long b0 = ((long)blockIdx.x * GQ_WAVES + wave) * 16;
@@ -52,10 +62,10 @@ __global__ __launch_bounds__(64 * GQ_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const bool mvalid = bm < A.B;
     const double *drow = A.out + (mvalid ? bm : 0) * (long)A.out_stride + tg.off;
     const double *yobs = A.yobs + tg.off;
-    double q[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     const int ntiles = (n + 15) / 16;
     const int nchunk = (n + GQ_KC - 1) / GQ_KC;
-    for (int tb = 0; tb < ntiles; tb += NT) {
+    const int tb0 = SPLIT ? (int)blockIdx.y * NT : 0, tb1 = SPLIT ? tb0 + NT : ntiles;
+    for (int tb = tb0; tb < tb1; tb += NT) {
         double4_t acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; i++) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -90,29 +100,34 @@ __global__ __launch_bounds__(64 * GQ_WAVES) __attribute__((amdgpu_waves_per_eu(2
             }
             __syncthreads();
         }
-        // lane holds Y[model kq + 4r][col (tb+i)*16 + mrow]; dot with D over these columns
+        // lane holds Y[model kq + 4r][col (tb+i)*16 + mrow]; dot with D over the columns of each group
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const long bmod = b0 + kq + 4 * r;
-            const bool ok = bmod < A.B;
-            const double *dr = A.out + (ok ? bmod : 0) * (long)A.out_stride + tg.off;
+        for (int g = 0; g < NG; g++) {
+            const int grp = tb / GQ_NTG + g;             // (passes start at a multiple of GQ_NTG tiles)
+            if (grp * GQ_NTG >= ntiles) break;
 #pragma unroll
-            for (int i = 0; i < NT; i++) {
-                const int col = (tb + i) * 16 + mrow;
-                const double d = (ok && col < n) ? dr[col] - yobs[col] : 0.0;
-                q[r] += acc[i][r] * d;
-                s2[r] += d * d;
+            for (int r = 0; r < 4; r++) {
+                const long bmod = b0 + kq + 4 * r;
+                const bool ok = bmod < A.B;
+                const double *dr = A.out + (ok ? bmod : 0) * (long)A.out_stride + tg.off;
+                double q = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int i = g * GQ_NTG; i < (g + 1) * GQ_NTG && i < NT; i++) {
+                    const int col = (tb + i) * 16 + mrow;
+                    const double d = (ok && col < n) ? dr[col] - yobs[col] : 0.0;
+                    q += acc[i][r] * d;
+                    s2 += d * d;
+                }
+                for (int o = 8; o > 0; o >>= 1) {       // reduce over the 16 lanes sharing kq
+                    q += __shfl_xor(q, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (mrow == 0 && ok) {
+                    double *w = gq + (bmod * A.gq_groups + grp) * 2;
+                    w[0] = q; w[1] = s2;
+                }
             }
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        for (int o = 8; o > 0; o >>= 1) {               // reduce over the 16 lanes sharing kq
-            q[r] += __shfl_xor(q[r], o, 64);
-            s2[r] += __shfl_xor(s2[r], o, 64);
-        }
-        const long bmod = b0 + kq + 4 * r;
-        if (mrow == 0 && bmod < A.B) { gq[bmod * 2] = q[r]; gq[bmod * 2 + 1] = s2[r]; }
     }
 }
 
@@ -152,10 +167,12 @@ __global__ __launch_bounds__(LIKE_T) void like_kernel(LikeArgs A)
             // precomputed on the matrix cores (gauss_q_kernel)
             if (tid < LIKE_M) {
                 for (int w = 0; w < NW; w++) { red[tid][w][0] = 0.0; red[tid][w][1] = 0.0; }
-                if (tid < Mb) {
-                    const double *g = A.gq + ((long)t * A.B + (b0 + tid)) * 2;
-                    red[tid][0][1] = g[0];
-                    red[tid][0][0] = g[1];
+                if (tid < Mb) {                     // the partials of the target's column-tile groups, in group order
+                    const double *g = A.gq + ((long)t * A.B + (b0 + tid)) * 2 * A.gq_groups;
+                    double qq = 0.0, ss = 0.0;
+                    for (int k = 0; k < gq_groups_of(n); k++) { qq += g[2 * k]; ss += g[2 * k + 1]; }
+                    red[tid][0][1] = qq;
+                    red[tid][0][0] = ss;
                 }
             }
         } else if (tg.cov == 3) {
@@ -428,13 +445,23 @@ hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
             if (A.tg[t].cov == 3)
             {
                 const int nt = (A.tg[t].n + 15) / 16;
-                const dim3 g((A.B + 16 * GQ_WAVES - 1) / (16 * GQ_WAVES)), b(64 * GQ_WAVES);
-                double *gq = A.gq + (long)t * A.B * 2;
-                const int NTsel = nt <= 4 ? 4 : nt <= 8 ? 8 : 13;          // wider targets: passes of 13 tiles
-                const size_t lds = (size_t)2 * GQ_KC * NTsel * 16 * sizeof(double);   // <= 64 KiB
-                if (NTsel == 4) hipLaunchKernelGGL(gauss_q_kernel<4>, g, b, lds, stream, A, t, gq);
-                else if (NTsel == 8) hipLaunchKernelGGL(gauss_q_kernel<8>, g, b, lds, stream, A, t, gq);
-                else hipLaunchKernelGGL(gauss_q_kernel<13>, g, b, lds, stream, A, t, gq);
+                const dim3 b(64 * GQ_WAVES);
+                const unsigned gx = (unsigned)((A.B + 16 * GQ_WAVES - 1) / (16 * GQ_WAVES));
+                double *gq = A.gq + (long)t * A.B * 2 * A.gq_groups;
+                static const char *force = std::getenv("BH_GQ_FORM");        // "split" | "fused" (A/B)
+                const bool split = force ? force[0] == 's' : A.B <= 32768;
+                if (split) {
+                    const size_t lds = (size_t)2 * GQ_KC * GQ_NTG * 16 * sizeof(double);
+                    hipLaunchKernelGGL((gauss_q_kernel<GQ_NTG, true>), dim3(gx, gq_groups_of(A.tg[t].n)), b, lds, stream, A, t, gq);
+                } else {
+                    // a pass must start at a multiple of GQ_NTG tiles: 13 tiles only when one pass takes them all
+                    const int NTsel = nt <= 4 ? 4 : nt <= 8 ? 8 : nt <= 13 ? 13 : 12;
+                    const size_t lds = (size_t)2 * GQ_KC * NTsel * 16 * sizeof(double);   // <= 64 KiB
+                    if (NTsel == 4) hipLaunchKernelGGL((gauss_q_kernel<4, false>), dim3(gx), b, lds, stream, A, t, gq);
+                    else if (NTsel == 8) hipLaunchKernelGGL((gauss_q_kernel<8, false>), dim3(gx), b, lds, stream, A, t, gq);
+                    else if (NTsel == 13) hipLaunchKernelGGL((gauss_q_kernel<13, false>), dim3(gx), b, lds, stream, A, t, gq);
+                    else hipLaunchKernelGGL((gauss_q_kernel<12, false>), dim3(gx), b, lds, stream, A, t, gq);
+                }
             }
     }
     size_t lds = (size_t)LIKE_M * nmax * sizeof(double);

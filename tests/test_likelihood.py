@@ -170,7 +170,7 @@ def test_gpu_gauss_quadratic_form_all_tile_shapes(lib, n, B):
                                      for a in (out, yobs, noise, Rinv.ravel()))
     desc = (_lib.LikeTarget * 1)(_lib.LikeTarget(n, 3, _lib.COV_GAUSS, 0, 1.25))
     need = lib.bh_likelihood_workspace_bytes(B, 1, desc)
-    assert need == B * 2 * 8
+    assert need == B * 2 * 8 * (((n + 15) // 16 + 3) // 4)       # a (q, sum d^2) pair per model and group of four column tiles
     ws = torch.empty(need // 8, dtype=torch.float64, device=dev)
     for use_ws in (True, False):
         logL = torch.zeros(B, dtype=torch.float64, device=dev)
@@ -183,3 +183,40 @@ def test_gpu_gauss_quadratic_form_all_tile_shapes(lib, n, B):
         assert np.allclose(logL.cpu().numpy(), want, rtol=1e-11, atol=1e-9)
         assert np.allclose(mis.cpu().numpy()[:, 0], want_mis, rtol=1e-12)
         assert np.allclose(mis.cpu().numpy()[:, 1], want_mis, rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [201, 250, 60])
+def test_gpu_gauss_form_does_not_depend_on_the_batch(lib, n):
+    """The dense Gaussian product has two decompositions (like_kernel.hip: gauss_q_kernel) -- a workgroup per group of
+    four column tiles for small batches, all tiles in one workgroup for large ones -- that compute the very same
+    partial sums: the likelihood of a model must be the same bits whether it is evaluated in a batch of 40 000 (fused
+    form) or in one of 9 000 (split form).  Chains of a pool, and of the ranks of a sharded pool, rely on that."""
+    import torch
+    from bayhunter_amd import _lib
+    B = 40000
+    rs = np.random.RandomState(n)
+    out = rs.normal(size=(B, n))
+    yobs = rs.normal(size=n)
+    Rinv = rs.normal(size=(n, n)) / n
+    noise = np.stack([np.full(B, 0.9), rs.uniform(0.5, 2.0, B)], axis=1)
+    dev = torch.device('cuda')
+    t_yobs, t_aux = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (yobs, Rinv.ravel()))
+    desc = (_lib.LikeTarget * 1)(_lib.LikeTarget(n, 0, _lib.COV_GAUSS, 0, 0.0))
+
+    def run(lo, hi):
+        nb = hi - lo
+        t_out = torch.from_numpy(np.ascontiguousarray(out[lo:hi])).to(dev)
+        t_noise = torch.from_numpy(np.ascontiguousarray(noise[lo:hi])).to(dev)
+        need = lib.bh_likelihood_workspace_bytes(nb, 1, desc)
+        ws = torch.empty(need // 8, dtype=torch.float64, device=dev)
+        logL = torch.zeros(nb, dtype=torch.float64, device=dev)
+        mis = torch.zeros((nb, 2), dtype=torch.float64, device=dev)
+        _lib.check(lib.bh_likelihood_batch(nb, 1, desc, t_out.data_ptr(), n, None, 0, t_yobs.data_ptr(), t_noise.data_ptr(),
+                                           t_aux.data_ptr(), logL.data_ptr(), mis.data_ptr(), ws.data_ptr(), need, None))
+        torch.cuda.synchronize()
+        return logL.cpu().numpy(), mis.cpu().numpy()
+    big_l, big_m = run(0, B)
+    for lo, hi in ((0, 9000), (9000, 9017), (31000, 40000)):
+        l, m = run(lo, hi)
+        assert np.array_equal(l, big_l[lo:hi]) and np.array_equal(m, big_m[lo:hi]), (n, lo, hi)
