@@ -389,7 +389,8 @@ def sharded_chain_pools(rank, world, ranks, backend):
                                  axis=2).astype(np.float32)          # rows x width float32
         t_payload = torch.from_numpy(payload).to(dev)
         nbytes_rank = payload.nbytes
-        gather_rows_to_root(t_payload, total)                         # first-use costs of the transport (untimed)
+        gather_rows_to_root(t_payload, total)                         # first-use costs of the transport (connections,
+        gather_rows(t_payload, total)                                 # staging buffers), both patterns, untimed
         full, t_root = timed(lambda: gather_rows_to_root(t_payload, total))
         _, t_all = timed(lambda: gather_rows(t_payload, total))
         blocks, t_blocks = timed(lambda: pool.gather())
