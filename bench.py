@@ -332,13 +332,15 @@ def chain_digest(blocks):
     return h.hexdigest()[:16]
 
 
-def sharded_chain_pools(rank, world, ranks, backend):
+def sharded_chain_pools(rank, world, ranks, backend, workloads=None, evaluator=None):
     """N > 1: the sampler as BASELINE.json words it -- cfg4 (64 chains per GPU, models of up to 15 layers) and cfg5
     (per-GPU pools, ragged 2-31 layers) with the chains block-sharded over the ranks and NO collective while
     sampling (reference: one process per chain, src/mcmcOptimizer.py:238-252) -- and then the one exchange the
     reference has: the per-chain sample blocks (its shared arrays, src/mcmcOptimizer.py:92-125, merged by
     src/Plotting.py:161-262) gathered over the process group (RCCL with backend nccl): to the root, raw and
-    thinned, and as an all-gather for comparison.  Returns (chain_pool_sharded, gather) for rank 0's line."""
+    thinned, and as an all-gather for comparison.  Returns (chain_pool_sharded, gather) for rank 0's line.
+    `workloads` / `evaluator` (test hooks): other pool sizes, and a likelihood function in place of the device's --
+    the CPU tier runs these legs over gloo with a made-up likelihood (tests/test_distributed.py)."""
     import torch
     import torch.distributed as dist
     from bayhunter_amd.chains import ChainPool
@@ -358,19 +360,19 @@ def sharded_chain_pools(rank, world, ranks, backend):
 
     pools_rec, gather_rec = {}, {}
     for name in ('cfg4', 'cfg5'):
-        wl = CHAIN_WORKLOADS[name]
+        wl = (workloads or CHAIN_WORKLOADS)[name]
         joint, priors = chain_setup(wl['layers'])
         ip = dict(CHAIN_IP, iter_burnin=wl['burnin'], iter_main=wl['main'])
         total = wl['chains_per_gpu'] * world
         seeds = np.arange(total) % 1000
         shard = (rank, world)
         with ChainPool(joint, initparams=dict(ip, iter_burnin=6, iter_main=2), modelpriors=priors, seeds=seeds,
-                       nmodels=9, shard=shard) as warm:
+                       nmodels=9, shard=shard, evaluator=evaluator) as warm:
             warm.run()
         time.sleep(BLAS_SETTLE_S)
         best = None
         for _ in range(3 if name == 'cfg4' else 2):
-            pool = ChainPool(joint, initparams=ip, modelpriors=priors, seeds=seeds, shard=shard)
+            pool = ChainPool(joint, initparams=ip, modelpriors=priors, seeds=seeds, shard=shard, evaluator=evaluator)
             _, dt = timed(lambda: pool.run())
             pool.close()
             if best is None or dt < best[0]:

@@ -242,3 +242,65 @@ def test_gloo_subgroup_gathers_address_the_right_peers():
     assert rag3 is None and [a.shape for a in rag1] == [(2, 3), (3, 3)]
     assert (rag1[0] == 1).all() and (rag1[1] == 3).all()
     assert t1 == 3.0 and t3 == 3.0
+
+
+# ---- bench.py's N > 1 legs (sharded sampler + timed gather) over gloo, with a made-up likelihood ----------
+def _made_up_likelihood(packed, nlay, noise):
+    return -60.0 * (packed[:, 2, 0] - 3.1) ** 2 - 1e-3 * nlay, np.zeros((packed.shape[0], 3))
+
+
+_TINY = {'cfg4': dict(layers=(1, 14), chains_per_gpu=5, burnin=30, main=20),
+         'cfg5': dict(layers=(1, 30), chains_per_gpu=9, burnin=30, main=20)}
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    bench.BLAS_SETTLE_S = 0.0
+    ranks = bench.Ranks(world, 'gloo', 0)
+    pools, gather = bench.sharded_chain_pools(rank, world, ranks, 'gloo', workloads=_TINY, evaluator=_made_up_likelihood)
+    if rank == 0:
+        q.put((pools, gather))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_bench_sharded_sampler_and_gather():
+    """What `bench.py --gpus N` adds to its line for N > 1 (bench.py: sharded_chain_pools) -- BASELINE cfg4 / cfg5 as
+    chain pools block-sharded over the ranks, then the pool's sample blocks gathered over the process group, to the
+    root and as an all-gather, raw and thinned -- run on the CPU tier by two gloo ranks with a made-up likelihood in
+    place of the device: the record has every field, the byte counts are the payload's, and the gathered chains are
+    the chains ONE process produces for the same seeds (digest)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    pools, gather = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    import bench
+    from bayhunter_amd.chains import ChainPool
+    for name, wl in _TINY.items():
+        total = 2 * wl['chains_per_gpu']
+        sh, g = pools[name], gather[name]
+        assert sh['nchains'] == total and sh['value'] > 0 and sh['iterations'] == 50 and sh['models_evaluated'] > 0
+        nmodels = 50                                           # int(iterations * max(acceptance) / 100), acceptance (40, 100)
+        width = 2 * (wl['layers'][1] + 1) + 3 + 1 + 4 + 1
+        assert g['bytes_per_rank'] == wl['chains_per_gpu'] * nmodels * width * 4 == g['bytes_received_by_root']
+        assert g['backend'] == 'gloo' and g['to_root']['ms'] > 0 and g['all_gather']['GB/s'] > 0
+        assert g['ChainPool.gather_final']['rows_at_root'] > 0
+        joint, priors = bench.chain_setup(wl['layers'])
+        ip = dict(bench.CHAIN_IP, iter_burnin=wl['burnin'], iter_main=wl['main'])
+        with ChainPool(joint, initparams=ip, modelpriors=priors, seeds=np.arange(total) % 1000,
+                       evaluator=_made_up_likelihood) as one:
+            one.run()
+        blocks = dict(models=one.models, likes=one.likes, iter=one.iter, noise=one.noise, vpvs=one.vpvs,
+                      naccepted=one.counters()[0])
+        assert bench.chain_digest(blocks) == g['chains_sha256'] and int(blocks['naccepted'].sum()) == g['accepted_total']
