@@ -702,13 +702,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             fin = S.st == SWD_ST_DONE;
             BH_TP(0);
             if (!fin) {
-                if (first) {
-                    const int nlm0 = S.mmax - S.llw;
-                    cap = nlm0 > 0 ? NL / nlm0 : SWD_TEAMW_NT;
-                    if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;        // one quad per Rayleigh trial
-                    if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
-                    if (cap < 1) cap = 1;
-                }
+                if (first) cap = swd_teamw_cap(S.mmax - S.llw, W, tg.iwave);
                 R = swd_teamw_round(S, tg, perl, cap, nxt);
                 nt = R.nt;
                 BH_TP(13);
@@ -729,10 +723,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         const int nlm = S.mmax - S.llw;
         if (first) {          // slots per round, and which (trial, layer) this lane assembles
             first = false;
-            cap = nlm > 0 ? NL / nlm : SWD_TEAMW_NT;
-            if (tg.iwave == 2 && cap > 16 * W) cap = 16 * W;
-            if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
-            if (cap < 1) cap = 1;
+            cap = swd_teamw_cap(nlm, W, tg.iwave);
 // (lanes of a wave hold the layers of few trials.  Layer-major -- a wave holding one or two layers for
             // many trials, so that it runs one branch of `var` instead of both -- was measured: 1 % faster on 15
             // layers x 512 lanes, 8 % slower on 5 layers x 64 lanes; same-box A/B, profiles/r03_ab_team.txt)

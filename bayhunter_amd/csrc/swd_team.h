@@ -234,6 +234,21 @@ enum { SWD_MAT = 20 };
 enum { SWD_PITCH = 21 };
 BH_HD int swd_mat_off(int s) { return s * SWD_PITCH; }
 
+// Slots per round of a team of W waves for models with nlm layers above the half-space: cell (j, r) -- layer r of
+// trial j -- is assembled by lane j * nlm + r of the whole team, quad q of wave w chains trial 16 w + q.
+// (Round 4 tried dealing the trials wave by wave -- wave w assembles AND chains trials w * tpw ..., which removes
+// the workgroup barrier between the two phases: cfg4 0.600 -> 0.681 ms, cfg5 8.09 -> 9.28 ms.  With 64 / nlm trials
+// per wave every wave walks through the chain at a quarter of its quads, eight waves on four SIMDs, where the
+// dealing above fills three waves and lets five skip it.)
+BH_HD int swd_teamw_cap(int nlm, int W, int iwave)
+{
+    const int NL = 64 * W;
+    int cap = nlm > 0 ? NL / nlm : (int)SWD_TEAMW_NT;
+    if (iwave == 2 && cap > 16 * W) cap = 16 * W;             // one quad per Rayleigh trial
+    if (cap > SWD_TEAMW_NT) cap = SWD_TEAMW_NT;
+    return cap < 1 ? 1 : cap;
+}
+
 // floor(log2(x)) for x >= 1
 BH_DEV int swd_ilog2(int x) { return 31 - __builtin_clz((unsigned)x); }
 

@@ -172,8 +172,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         bh::swd_driver(S, lay, src, tg, t, 1);
         if (S.st == bh::SWD_ST_DONE) break;
         const int nlm = S.mmax - S.llw;
-        int cap = nlm > 0 ? nlanes / nlm : NT;
-        if (cap > nlanes / 4) cap = nlanes / 4;           // one quad per Rayleigh trial
+        const int cap = bh::swd_teamw_cap(nlm, nlanes / 64, iwave);        // (the device's slots per round)
         const bh::TeamwRound R = bh::swd_teamw_round(S, tg, t, cap, nxt);
         const int nt = R.nt;
         if (nt < 1 || nt > NT || nt > (cap > 1 ? cap : 1)) return -100;      // layout invariants

@@ -18,6 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 SHAPES = [  # name, layers, periods, lanes, igr
     ('cfg2  5 layers x 64 lanes', 5, 20, 64, 0),
+    ('cfg2  5 layers x 128 lanes', 5, 20, 128, 0),
+    ('cfg2  5 layers x 256 lanes', 5, 20, 256, 0),
     ('pool 10 layers x 64 lanes', 10, 21, 64, 0),
     ('cfg5 ragged x 128 lanes', (2, 31), 21, 128, 0),
     ('cfg4 15 layers x 256 lanes', 15, 21, 256, 0),
