@@ -163,6 +163,8 @@ _SIGS = {
     "bh_eval_buffers": (C.c_int, [_vp] + [C.POINTER(_vp)] * 5),
     "bh_eval_submit": (C.c_int, [_vp, C.c_int]),
     "bh_eval_wait": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "bh_eval_set_concurrency": (C.c_int, [_vp, C.c_int]),
+    "bh_swd_hint": (C.c_int, [C.c_double, C.c_int]),
     "bh_version": (C.c_char_p, []),
     "bh_last_error": (C.c_char_p, []),
     "bh_device_count": (C.c_int, [C.POINTER(C.c_int)]),

@@ -105,6 +105,10 @@ class GpuEvaluator(object):
                 del self._plans[key]
                 plan.close()
 
+    def set_concurrency(self, n):
+        for plan in self._plans.values():
+            plan.set_concurrency(n)
+
     def close(self):
         for plan in self._plans.values():
             plan.close()
@@ -255,6 +259,8 @@ class ChainPool(object):
         bounds = [(g * self.nchains) // groups for g in range(groups + 1)]
         self.groups = [_Group(self.lib, self.cfg, self.seeds, arrays, bounds[g], bounds[g + 1], self.Lmax,
                               evaluator, self.ntargets) for g in range(groups)]
+        if hasattr(evaluator, 'set_concurrency'):          # the groups' batches alternate on the device
+            evaluator.set_concurrency(len(self.groups))
         if nthreads is not None:
             for g in self.groups:
                 _lib.check(self.lib.bh_chains_set_threads(g.handle, int(nthreads)))

@@ -335,6 +335,10 @@ std::atomic<int> g_swd_mode{BH_SWD_AUTO};
 thread_local int g_last_form = -1;
 thread_local int g_last_forms[bh::BH_NT] = {0};   // per target (bh_swd_last_forms)
 thread_local int g_forced_forms[bh::BH_NT] = {0};
+// what the caller knows about its next batch and the planner cannot see in device memory (bh_swd_hint): the mean
+// layer count of the models (0: unknown) and how many such calls are in flight together (>= 1)
+thread_local double g_hint_mean = 0.0;
+thread_local int g_hint_load = 1;
 thread_local int g_nforced = 0;                    // > 0: bh_swd_set_forms is in force for calls with that many targets    // what the last bh_swd_batch of this thread launched (bh_swd_last_form)
 
 long team_threshold()
@@ -368,7 +372,16 @@ double target_weight(const bh_swd_target &s)
 // 10 % or more (same example: 17.0 ms).  Nothing else is moved: with more models the teams share SIMDs and lose
 // more than the lane kernel gains, and moves between team forms measured worse throughout (tools/auto_forms.py,
 // tools/forced_forms.py, profiles/r03_mixed_forms.txt).  BH_SWD_NO_MIXED=1 keeps one form per call (A/B).
-void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, long cus, int swd_mode, int *width)
+// Depth.  The table is measured on batches of one depth.  A sampler's batch is ragged -- proposals of a tutorial
+// pool have 2 to 14 layers, 4.8 on average -- and taking the regime of its DEEPEST model prices every search as
+// deep as that one: the planner put pools of 8 192 and 16 384 chains on 128-lane teams where 64-lane teams are 35 %
+// faster (profiles/r04_pool_forms.txt).  With the mean layer count known (bh_swd_hint; the evaluation plan and the
+// engine know it from the host's copy of nlay) a form costs max(its latency on the deepest model, its time for all
+// searches at the mean depth): the deep minority is started first (processing order) and bounds the call from
+// below, the rest is throughput.  `load` calls in flight together (the chain groups of a pool alternate on the
+// device) share the chip: the throughput term is read at load x searches.
+void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, long cus, int swd_mode, int *width,
+                double mean_layers = 0.0, int load = 1)
 {
     if (g_nforced == ntargets) {                       // bh_swd_set_forms (tests, experiments)
         for (int t = 0; t < ntargets; t++) width[t] = g_forced_forms[t];
@@ -381,7 +394,10 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
         for (int t = 0; t < ntargets; t++) width[t] = w;
         return;
     }
-    const int regime = Lmax <= 3 ? 0 : Lmax <= 6 ? 1 : Lmax <= 12 ? 2 : Lmax <= 20 ? 3 : 4;
+    auto regime_of = [](double L) { return L <= 3 ? 0 : L <= 6 ? 1 : L <= 12 ? 2 : L <= 20 ? 3 : 4; };
+    const int regime = regime_of((double)Lmax);
+    const int regime_thr = (mean_layers > 0.0 && mean_layers < (double)Lmax) ? regime_of(mean_layers) : regime;
+    if (load < 1) load = 1;
     const long searches = (long)B * ntargets;
     const double scale = 256.0 / (double)cus;                  // the table's chip has 256 CUs
     auto allowed = [&](int k) {
@@ -394,6 +410,18 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
         int n = bh::kFormSizes;
         while (n > 1 && bh::kFormMs[regime][k][n - 1] < 0) n--;
         return n;
+    };
+    auto form_ms_in = [&](int rg, int k, double s) {
+        const float *t = bh::kFormMs[rg][k], *S = bh::kFormSearches;
+        int n = bh::kFormSizes;
+        while (n > 1 && t[n - 1] < 0) n--;
+        if (s <= S[0]) return (double)t[0];
+        if (s > S[n - 1]) return n < bh::kFormSizes ? 1e300 : (double)t[n - 1] * s / S[n - 1];
+        if (s == S[n - 1]) return (double)t[n - 1];
+        int i = 0;
+        while (S[i + 1] <= s) i++;
+        const double f = (std::log(s) - std::log(S[i])) / (std::log(S[i + 1]) - std::log(S[i]));
+        return t[i] + f * (t[i + 1] - t[i]);
     };
     auto form_ms = [&](int k, double s) {
         const float *t = bh::kFormMs[regime][k], *S = bh::kFormSearches;
@@ -410,7 +438,9 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
     double best = 1e300;
     for (int k = 0; k < 8; k++) {
         if (!allowed(k)) continue;
-        const double cost = form_ms(k, (double)searches * scale);
+        double cost = form_ms(k, (double)searches * scale);
+        if (regime_thr != regime || load > 1)         // ragged batch / shared chip: latency of the deepest | throughput
+            cost = std::fmax((double)bh::kFormMs[regime][k][0], form_ms_in(regime_thr, k, (double)searches * scale * load));
         if (cost < best) { best = cost; uniform = k; }
     }
     int form[bh::BH_NT];
@@ -562,7 +592,8 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     if (rc) return rc;
     const long cus = resident > 0 ? resident / 8 : 256;
     int width[bh::BH_NT];
-    plan_forms(B, Lmax, ntargets, targets, cus, g_swd_mode.load(std::memory_order_relaxed), width);
+    plan_forms(B, Lmax, ntargets, targets, cus, g_swd_mode.load(std::memory_order_relaxed), width, g_hint_mean, g_hint_load);
+    g_hint_mean = 0.0; g_hint_load = 1;             // a hint is about ONE call
     // one launch per kernel form; the form with the heaviest target goes first, on the caller's stream
     struct Launch { int width, n; double weight; unsigned char sel[bh::BH_NT]; };
     Launch launches[bh::BH_NT];
@@ -634,7 +665,17 @@ int bh_swd_plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *target
 {
     if (B < 1 || Lmax < 1 || Lmax > BH_MAX_LAYERS || ntargets < 1 || ntargets > BH_MAX_TARGETS || !targets || !forms)
         return fail_arg("bh_swd_plan_forms: bad argument");
-    plan_forms(B, Lmax, ntargets, targets, cus > 0 ? cus : 256, g_swd_mode.load(std::memory_order_relaxed), forms);
+    plan_forms(B, Lmax, ntargets, targets, cus > 0 ? cus : 256, g_swd_mode.load(std::memory_order_relaxed), forms,
+               g_hint_mean, g_hint_load);
+    g_hint_mean = 0.0; g_hint_load = 1;
+    return BH_OK;
+}
+
+int bh_swd_hint(double mean_layers, int concurrent_calls)
+{
+    if (!(mean_layers >= 0.0) || concurrent_calls < 1) return fail_arg("bh_swd_hint: mean_layers >= 0, concurrent_calls >= 1");
+    g_hint_mean = mean_layers;
+    g_hint_load = concurrent_calls;
     return BH_OK;
 }
 

@@ -91,6 +91,7 @@ struct bh_eval_plan {
     size_t sort_bytes = 0, like_bytes = 0, swd_bytes = 0;
     hipStream_t st = nullptr, side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, done = nullptr;
+    int concurrency = 1;          // plans taking turns on the device (bh_eval_set_concurrency)
     int last_count = 0;           // models of the submission `done` belongs to (set once `done` is recorded)
     bool failed = false;          // the last submission returned an error: nothing to wait for, no results
     std::string failure;
@@ -257,7 +258,8 @@ static int submit_batch(bh_eval_plan *p, int count, bool *forked)
     const int L = p->Lmax, T = p->T;
     const int *hnlay = (const int *)(p->hblock + p->off_nlay);
     int depth = 1;
-    for (int i = 0; i < count; i++) depth = std::max(depth, hnlay[i]);
+    long layers = 0;
+    for (int i = 0; i < count; i++) { depth = std::max(depth, hnlay[i]); layers += hnlay[i] > 0 ? hnlay[i] : 0; }
     // the kernels size their LDS images by the deepest model of the batch (even, so that rows can be
     // fetched two layers at a time), not by the allocated row length
     const int Leff = std::min(L, depth + (depth & 1));
@@ -291,6 +293,8 @@ static int submit_batch(bh_eval_plan *p, int count, bool *forked)
                                              (size_t)count, 0, 32, p->st));
             order = p->order;
         }
+        // the batch is ragged: the planner prices it by its mean depth, not by its deepest model (capi.hip: plan_forms)
+        if ((rc = bh_swd_hint((double)layers / (double)count, p->concurrency))) return rc;
         if ((rc = bh_swd_batch_ordered(count, Leff, 4 * L, dnlay, h, vp, vs, rho, p->nswd, p->swd.data(), p->periods,
                                        p->out, p->row, p->err, order, p->swd_ws, p->swd_bytes, p->st)))
             return rc;
@@ -343,6 +347,13 @@ int bh_eval_submit(bh_eval_plan *p, int count)
         return rc;
     }
     p->last_count = count;                            // only now: `done` has been recorded for this batch
+    return BH_OK;
+}
+
+int bh_eval_set_concurrency(bh_eval_plan *p, int plans_in_flight)
+{
+    if (!p || plans_in_flight < 1) return bh::fail_arg_("bh_eval_set_concurrency: bad argument");
+    p->concurrency = plans_in_flight;
     return BH_OK;
 }
 

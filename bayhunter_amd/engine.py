@@ -18,10 +18,13 @@ class DeviceModels(object):
     """A batch of layered models resident in HBM: `packed` is [B, 4, Lmax] fp64 (h, vp, vs, rho
     rows of each model contiguous, zero padded), `nlay` int32 [B].  H/VP/VS/RHO are views."""
 
-    def __init__(self, packed, nlay, order=None, depth=None):
+    def __init__(self, packed, nlay, order=None, depth=None, mean_depth=None):
         assert packed.dim() == 3 and packed.shape[1] == 4 and packed.is_contiguous()
         self.packed, self.nlay = packed, nlay
         self.B, self.Lmax = packed.shape[0], packed.shape[2]
+        # mean layer count when the host knows it: a ragged batch is priced by it, not by its deepest model
+        # (bh_swd_hint)
+        self.mean_depth = None if mean_depth is None else float(mean_depth)
         # deepest model of the batch when the host knows it (<= Lmax): the kernels size their LDS
         # images and pick the team width by it instead of by the allocated row length
         self.depth = None if depth is None else max(1, min(int(depth), self.Lmax))
@@ -86,11 +89,13 @@ class ForwardEngine(object):
         f64 = torch.float64
         parts = [self._as_dev(x, f64) for x in (H, VP, VS, RHO)]
         packed = torch.stack(parts, dim=1).contiguous()
-        depth = int(np.max(nlay)) if isinstance(nlay, np.ndarray) and nlay.size else None
+        known = isinstance(nlay, np.ndarray) and nlay.size
+        depth = int(np.max(nlay)) if known else None
+        mean = float(np.mean(np.clip(nlay, 0, None))) if known else None
         nlay = self._as_dev(nlay, torch.int32)
-        return self.reorder(packed, nlay, depth=depth)
+        return self.reorder(packed, nlay, depth=depth, mean_depth=mean)
 
-    def reorder(self, packed, nlay, ragged=None, depth=None):
+    def reorder(self, packed, nlay, ragged=None, depth=None, mean_depth=None):
         """DeviceModels for a packed [B, 4, Lmax] device tensor, with a processing order for large
         batches.  Three keys, one sort (no data move; bh_swd_batch_ordered takes the permutation):
           1. deepest models first: the layer loop of a wave runs to its deepest model;
@@ -115,7 +120,7 @@ class ForwardEngine(object):
                     B, L, 4 * L, nlay.data_ptr(), packed[:, 0, :].data_ptr(), packed[:, 2, :].data_ptr(),
                     tmax, 1 if self.order_by_length else 0, keys.data_ptr(), C.c_void_p(st.cuda_stream)))
             order = torch.argsort(keys).to(torch.int32)
-        return DeviceModels(packed, nlay, order, depth)
+        return DeviceModels(packed, nlay, order, depth, mean_depth)
 
     def alloc_out(self, B):
         out = torch.empty((B, self.row), dtype=torch.float64, device=self.device)
@@ -168,6 +173,8 @@ class ForwardEngine(object):
                             ws = self._ws[st.cuda_stream] = torch.empty((need + 7) // 8, dtype=torch.float64,
                                                                         device=self.device)
                     ws_ptr = ws.data_ptr()
+                if models.mean_depth is not None:
+                    _lib.check(self.lib.bh_swd_hint(models.mean_depth, 1))
                 _lib.check(self.lib.bh_swd_batch_ordered(
                     B, Lmax, mstride, nlay.data_ptr(), H.data_ptr(), VP.data_ptr(), VS.data_ptr(),
                     RHO.data_ptr(), len(self.swd), self._tg, self.periods.data_ptr(),

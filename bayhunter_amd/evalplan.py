@@ -59,6 +59,11 @@ class EvalPlan(object):
     def submit(self, count):
         _lib.check(self.lib.bh_eval_submit(self._live(), int(count)))
 
+    def set_concurrency(self, plans_in_flight):
+        """How many plans take turns on the device (the chain groups of a pool): the library chooses its kernel
+        forms for that load."""
+        _lib.check(self.lib.bh_eval_set_concurrency(self._live(), int(plans_in_flight)))
+
     def wait(self):
         self._live()
         n = C.c_int(0)

@@ -477,7 +477,7 @@ def run_workload(name, B, rank, ranks, steps, warmup, serial=False, budget_s=Non
     def step():
         # a sampler brings new models every step: the processing order (a sort by depth and S travel
         # time, engine.reorder) is part of the step, not of the upload
-        eng.run(eng.reorder(dmodels.packed, dmodels.nlay, depth=dmodels.depth), out=out, err=err)
+        eng.run(eng.reorder(dmodels.packed, dmodels.nlay, depth=dmodels.depth, mean_depth=dmodels.mean_depth), out=out, err=err)
 
     for _ in range(warmup):
         step()

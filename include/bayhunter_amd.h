@@ -124,6 +124,13 @@ int bh_swd_set_forms(const int *forms, int ntargets);
 /* The same choice without a launch (host only, no device needed): forms[t] for a call with B models of at
  * most Lmax layers on a device with `cus` compute units (<= 0: 256). */
 int bh_swd_plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, int cus, int *forms);
+/* What the caller knows about its NEXT dispersion call on this thread (bh_swd_batch*, bh_swd_plan_forms) and the
+ * library cannot see in device memory: the mean layer count of the batch's models (0: unknown -- the deepest model
+ * then stands for all, which is right for batches of one depth and pessimistic for a sampler's ragged ones) and the
+ * number of such calls in flight on the device together (>= 1; the chain groups of a pool alternate).  The kernel
+ * form is chosen with them; results never depend on it.  The evaluation plan and ForwardEngine.upload give the hint
+ * themselves. */
+int bh_swd_hint(double mean_layers, int concurrent_calls);
 int bh_swd_batch(int B, int Lmax, int model_stride, const int *nlay, const double *h,
                  const double *vp, const double *vs, const double *rho, int ntargets,
                  const bh_swd_target *targets,
@@ -381,6 +388,9 @@ int  bh_eval_buffers(bh_eval_plan *plan, double **packed, int **nlay, double **n
                      double **results);
 int  bh_eval_submit(bh_eval_plan *plan, int count);
 int  bh_eval_wait(bh_eval_plan *plan, int *count);   /* blocks until the last submission has landed */
+/* How many plans take turns on the device (a pool's chain groups; default 1): passed on as bh_swd_hint's second
+ * argument with every submission. */
+int  bh_eval_set_concurrency(bh_eval_plan *plan, int plans_in_flight);
 
 /* ---- plumbing for hosts without their own device allocator ------------------------------ */
 int bh_malloc(void **dptr, size_t bytes);

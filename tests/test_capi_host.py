@@ -182,6 +182,20 @@ def test_form_plan_moves_the_heaviest_target_of_a_latency_bound_call():
     assert plan(8192, 10, cfg3) == [0, 128, 0, 0] and plan(8192, 5, cfg3) == [0, 8, 0, 0]
     assert plan(64, 10, cfg3) == [512] * 4 and plan(524288, 10, cfg3) == [0] * 4
     assert plan(12288, 10, [(2, 0, 21)]) == [64] and plan(524288, 10, [(2, 0, 21)]) == [0]
+    # a sampler's ragged batch (proposals of a tutorial pool: 2-14 layers, 4.8 on average): priced by its mean depth and
+    # by the number of batches in flight once the caller says so (bh_swd_hint), by its deepest model otherwise
+    one = [(2, 0, 21)]
+    assert plan(4096, 14, one) == [128]
+    _lib.check(lib.bh_swd_hint(4.8, 2))
+    assert plan(4096, 14, one) == [64]
+    assert plan(4096, 14, one) == [128]                      # a hint is about one call
+    _lib.check(lib.bh_swd_hint(4.8, 1))
+    assert plan(8192, 14, one) == [64]
+    _lib.check(lib.bh_swd_hint(4.8, 1))
+    assert plan(2048, 14, one) == [128]                      # the deepest model's latency still bounds a small batch
+    _lib.check(lib.bh_swd_hint(16.75, 1))
+    assert plan(8192, 31, one) == [128]                      # BASELINE cfg5: unchanged
+    assert lib.bh_swd_hint(-1.0, 1) != 0 and lib.bh_swd_hint(3.0, 0) != 0
     for B in (1, 64, 1024, 8192, 65536):
         for L in (3, 10, 30):
             f = plan(B, L, cfg3)
