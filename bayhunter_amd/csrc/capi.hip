@@ -558,6 +558,9 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
                          int out_stride, int *err, const int *order, void *workspace,
                          size_t workspace_bytes, void *stream)
 {
+    const double hint_mean = g_hint_mean;              // a hint is about ONE call, whatever becomes of it
+    const int hint_load = g_hint_load;
+    g_hint_mean = 0.0; g_hint_load = 1;
     if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail_arg("B/Lmax out of range");
     if (model_stride < Lmax) return fail_arg("model_stride < Lmax");
     if (ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("ntargets out of range");
@@ -592,8 +595,7 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
     if (rc) return rc;
     const long cus = resident > 0 ? resident / 8 : 256;
     int width[bh::BH_NT];
-    plan_forms(B, Lmax, ntargets, targets, cus, g_swd_mode.load(std::memory_order_relaxed), width, g_hint_mean, g_hint_load);
-    g_hint_mean = 0.0; g_hint_load = 1;             // a hint is about ONE call
+    plan_forms(B, Lmax, ntargets, targets, cus, g_swd_mode.load(std::memory_order_relaxed), width, hint_mean, hint_load);
     // one launch per kernel form; the form with the heaviest target goes first, on the caller's stream
     struct Launch { int width, n; double weight; unsigned char sel[bh::BH_NT]; };
     Launch launches[bh::BH_NT];
@@ -663,11 +665,13 @@ int bh_swd_last_form(void) { return g_last_form; }
 
 int bh_swd_plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, int cus, int *forms)
 {
+    const double hint_mean = g_hint_mean;
+    const int hint_load = g_hint_load;
+    g_hint_mean = 0.0; g_hint_load = 1;
     if (B < 1 || Lmax < 1 || Lmax > BH_MAX_LAYERS || ntargets < 1 || ntargets > BH_MAX_TARGETS || !targets || !forms)
         return fail_arg("bh_swd_plan_forms: bad argument");
     plan_forms(B, Lmax, ntargets, targets, cus > 0 ? cus : 256, g_swd_mode.load(std::memory_order_relaxed), forms,
-               g_hint_mean, g_hint_load);
-    g_hint_mean = 0.0; g_hint_load = 1;
+               hint_mean, hint_load);
     return BH_OK;
 }
 

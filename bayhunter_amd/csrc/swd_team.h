@@ -664,11 +664,6 @@ struct TeamwNode {
     double c1, d1, c2, d2;
     double c3n;
 };
-// slot the search was at before it arrived at node j (> 0)
-BH_DEV int swd_teamw_parent(const TeamwRound &R, int j)
-{
-    return R.chains ? (j <= 2 ? 0 : j - 2) : (j - 1) >> 1;
-}
 // `v.del(slot)`, `v.c(slot)`: period-equation value and trial velocity of a slot
 template <class V>
 BH_DEV TeamwNode swd_teamw_node(const SwdState &S, const TeamwRound &R, const V &v, int j)
