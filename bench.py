@@ -304,9 +304,8 @@ def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
     with ChainPool(joint, initparams=dict(ip, iter_burnin=6, iter_main=2), modelpriors=priors, seeds=seeds, nmodels=9) as warm:
         warm.run()
     time.sleep(BLAS_SETTLE_S)
-    # three samples, the best one reported (all three in the record): single stalls of 10-80 ms on the host side
-    # -- the box's CPU quota period running out under the pool's spinning helpers and the HIP runtime's threads
-    # -- are a third of one 0.3 s sample when they fall into it
+    # three samples, the best one reported (all three in the record; since the set-up's BLAS spin is kept out of
+    # them -- BLAS_SETTLE_S -- they agree within a few per cent)
     runs = []
     for _ in range(3):
         with ChainPool(joint, initparams=ip, modelpriors=priors, seeds=seeds) as pool:
