@@ -192,6 +192,8 @@ _SIGS = {
     "bh_likelihood_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(LikeTarget)]),
     "bh_likelihood_batch": (C.c_int, [C.c_int, C.c_int, C.POINTER(LikeTarget), _vp, C.c_int, _vp,
                                       C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "bh_likelihood_stage": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(LikeTarget), _vp, C.c_int, _vp,
+                                      C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "bh_surfdisp96": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, _vp, _vp, C.POINTER(C.c_int)]),
     "bh_synrf": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -820,6 +820,16 @@ int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, cons
                         const double *noise, const double *aux, double *logL, double *misfits,
                         void *workspace, size_t workspace_bytes, void *stream)
 {
+    return bh_likelihood_stage(BH_LIKE_STAGE_GAUSS | BH_LIKE_STAGE_REST, B, ntargets, targets, out, out_stride, err, nflags,
+                               yobs, noise, aux, logL, misfits, workspace, workspace_bytes, stream);
+}
+
+int bh_likelihood_stage(int stages, int B, int ntargets, const bh_like_target *targets, const double *out,
+                        int out_stride, const int *err, int nflags, const double *yobs,
+                        const double *noise, const double *aux, double *logL, double *misfits,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (stages < 1 || stages > 3) return fail_arg("bh_likelihood_stage: stages is BH_LIKE_STAGE_GAUSS | BH_LIKE_STAGE_REST");
     if (B < 0 || ntargets < 1 || ntargets > BH_MAX_TARGETS) return fail_arg("B/ntargets out of range");
     if (B == 0) return BH_OK;
     if (!targets || !out || !yobs || !noise || !logL || !misfits) return fail_arg("NULL pointer");
@@ -845,7 +855,8 @@ int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, cons
     size_t need = bh_likelihood_workspace_bytes(B, ntargets, targets);
     A.gq = (need > 0 && workspace && workspace_bytes >= need) ? (double *)workspace : nullptr;
     A.gq_groups = (int)(need / ((size_t)ntargets * (size_t)B * 2 * sizeof(double)));
-    BH_HIP(bh::launch_like(A, nmax, (hipStream_t)stream));
+    if (stages != 3 && !A.gq) return fail_arg("bh_likelihood_stage: the stages can only be split with a workspace");
+    BH_HIP(bh::launch_like(A, nmax, (hipStream_t)stream, stages));
     return BH_OK;
 }
 

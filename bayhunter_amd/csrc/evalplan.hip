@@ -30,7 +30,6 @@ namespace {
     } while (0)
 
 constexpr int kOrderMin = 1024;   // up to this every team is resident at once: order is irrelevant (layout.py: ORDER_MIN)
-
 struct Interp {                   // numpy.interp(obsx, periods, solved values) for a target with > 60 periods
     int src_off, n_src, dst_off, n_dst;
     long long *j;                 // device tables [n_dst]
@@ -92,6 +91,8 @@ struct bh_eval_plan {
     hipStream_t st = nullptr, side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, done = nullptr;
     int concurrency = 1;          // plans taking turns on the device (bh_eval_set_concurrency)
+    bool gauss_on_side = false;   // every dense-Gaussian target is a receiver function's: its product runs behind
+                                  // rf_kernel on the side stream, beside the dispersion searches (bh_eval_submit)
     int last_count = 0;           // models of the submission `done` belongs to (set once `done` is recorded)
     bool failed = false;          // the last submission returned an error: nothing to wait for, no results
     std::string failure;
@@ -225,6 +226,18 @@ int bh_eval_create(int max_models, int Lmax, int row, int nswd, const bh_swd_tar
         hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess)
         return bail(bh::fail_hip_((int)hipErrorUnknown, "stream / event creation"));
+    if (p->like_bytes && nswd > 0 && nrf > 0) {
+        bool all_rf = true, any = false;
+        for (int t = 0; t < ntargets; t++) {
+            if (like[t].cov != BH_COV_GAUSS) continue;
+            any = true;
+            bool in_rf = false;
+            for (int i = 0; i < nrf; i++)
+                in_rf = in_rf || (like[t].off >= rf[i].out_off && like[t].off + like[t].n <= rf[i].out_off + rf[i].nout);
+            all_rf = all_rf && in_rf;
+        }
+        p->gauss_on_side = any && all_rf;
+    }
     hipLaunchKernelGGL(iota_kernel, dim3((max_models + 255) / 256), dim3(256), 0, p->st, max_models, p->iota);
     if (max_models > kOrderMin && nswd) {
         if (rocprim::radix_sort_pairs(nullptr, p->sort_bytes, p->keys, p->keys_out, p->iota, p->order,
@@ -312,14 +325,24 @@ static int submit_batch(bh_eval_plan *p, int count, bool *forked)
     for (const bh_rf_params &r : p->rf)
         if ((rc = bh_rf_batch(count, Leff, 4 * L, dnlay, h, vp, vs, rho, nullptr, nullptr, &r, p->out, p->row, nullptr, 0, rst)))
             return rc;
+    double *logL = p->dres, *mis = p->dres + count;
+    // The dense Gaussian product of a receiver-function target needs that target's columns only: it follows
+    // rf_kernel on the side stream, beside this batch's dispersion searches.  Behind the join it was on the critical
+    // path of every batch -- and, a short kernel that asks for four SIMDs' worth of registers at once, it waited a
+    // third of a millisecond for the OTHER chain group's teams to drain (rocprofv3 of a 4 096-chain pool: 0.31 ms per
+    // call where it takes 0.04 ms alone, 22 % of the kernel time).
+    const bool staged = overlap && p->gauss_on_side;
+    if (staged && (rc = bh_likelihood_stage(BH_LIKE_STAGE_GAUSS, count, T, p->like.data(), p->out, p->row, p->err, p->nflags,
+                                            p->yobs, dnoise, p->aux, logL, mis, p->like_ws, p->like_bytes, rst)))
+        return rc;
     if (overlap) {
         EP_HIP(hipEventRecord(p->join, p->side));
         EP_HIP(hipStreamWaitEvent(p->st, p->join, 0));
         *forked = false;                  // joined
     }
-    double *logL = p->dres, *mis = p->dres + count;
-    if ((rc = bh_likelihood_batch(count, T, p->like.data(), p->out, p->row, p->err, p->nflags, p->yobs, dnoise, p->aux,
-                                  logL, mis, p->like_ws, p->like_bytes, p->st)))
+    if ((rc = bh_likelihood_stage(staged ? BH_LIKE_STAGE_REST : (BH_LIKE_STAGE_GAUSS | BH_LIKE_STAGE_REST), count, T,
+                                  p->like.data(), p->out, p->row, p->err, p->nflags, p->yobs, dnoise, p->aux, logL, mis,
+                                  p->like_ws, p->like_bytes, p->st)))
         return rc;
     // results: [count] logL then [count][T+1] misfits, contiguous on both sides
     EP_HIP(hipMemcpyAsync(p->hres, p->dres, (size_t)count * (T + 2) * sizeof(double), hipMemcpyDeviceToHost, p->st));

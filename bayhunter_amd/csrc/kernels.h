@@ -88,7 +88,7 @@ struct LikeArgs {
 constexpr int GQ_NTG = 4;
 __host__ __device__ inline int gq_groups_of(int n) { return ((n + 15) / 16 + GQ_NTG - 1) / GQ_NTG; }
 
-hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream);
+hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream, int stages = 3);
 hipError_t launch_swd(const SwdArgs &A, int resident_waves, hipStream_t stream);
 hipError_t launch_swd_team(const SwdArgs &A, int team_lanes, int resident_waves, hipStream_t stream);
 size_t swd_team_lds_bytes(int Lmax, int team_lanes);

@@ -438,9 +438,11 @@ hipError_t launch_voronoi(const VoronoiArgs &A, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
+// stages: 1 = the dense Gaussian products (they need only the rows of their own targets: an evaluation plan runs
+// them behind the receiver-function kernel on its side stream, beside the dispersion searches), 2 = like_kernel
+hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream, int stages)
 {
-    if (A.gq) {   // dense Gaussian targets first, on the FP64 MFMA
+    if (A.gq && (stages & 1)) {   // dense Gaussian targets first, on the FP64 MFMA
         for (int t = 0; t < A.ntargets; t++)
             if (A.tg[t].cov == 3)
             {
@@ -464,6 +466,7 @@ hipError_t launch_like(const LikeArgs &A, int nmax, hipStream_t stream)
                 }
             }
     }
+    if (!(stages & 2)) return hipGetLastError();
     size_t lds = (size_t)LIKE_M * nmax * sizeof(double);
     static size_t lds_set[16] = {0};
     if (lds > 48 * 1024) {

@@ -222,6 +222,18 @@ int bh_likelihood_batch(int B, int ntargets, const bh_like_target *targets, cons
                         const double *noise, const double *aux, double *logL, double *misfits,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same in two stages, for a caller that overlaps them with other work: BH_LIKE_STAGE_GAUSS launches only the
+ * dense products of the BH_COV_GAUSS targets into the workspace (it reads the columns of those targets, yobs and
+ * aux: nothing else of the arguments needs to be ready), BH_LIKE_STAGE_REST the rest, which consumes them -- the
+ * caller orders the two (an evaluation plan runs the first behind the receiver-function kernel on its side
+ * stream, beside the dispersion searches).  Needs the workspace.  Both stages at once = bh_likelihood_batch. */
+#define BH_LIKE_STAGE_GAUSS 1
+#define BH_LIKE_STAGE_REST  2
+int bh_likelihood_stage(int stages, int B, int ntargets, const bh_like_target *targets, const double *out,
+                        int out_stride, const int *err, int nflags, const double *yobs,
+                        const double *noise, const double *aux, double *logL, double *misfits,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- single-model drop-ins (host pointers, synchronous) --------------------------------- */
 /* Same argument list as the f2py wrapper of `subroutine surfdisp96`; model arrays are real*4 with
  * at least nlayer valid entries, t/cg real*8 with at least kmax entries.  *err as the reference. */

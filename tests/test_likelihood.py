@@ -220,3 +220,41 @@ def test_gpu_gauss_form_does_not_depend_on_the_batch(lib, n):
     for lo, hi in ((0, 9000), (9000, 9017), (31000, 40000)):
         l, m = run(lo, hi)
         assert np.array_equal(l, big_l[lo:hi]) and np.array_equal(m, big_m[lo:hi]), (n, lo, hi)
+
+
+@pytest.mark.gpu
+def test_gpu_likelihood_in_two_stages_equals_one_call(lib):
+    """bh_likelihood_stage: the dense Gaussian products first (an evaluation plan runs them behind the
+    receiver-function kernel on its side stream, beside the dispersion searches), the rest afterwards -- the same
+    bits as bh_likelihood_batch; without a workspace the stages cannot be split."""
+    import torch
+    from bayhunter_amd import _lib
+    B, n1, n2 = 777, 21, 201
+    rs = np.random.RandomState(5)
+    out = rs.normal(size=(B, n1 + n2))
+    yobs = rs.normal(size=n1 + n2)
+    Rinv = rs.normal(size=(n2, n2)) / n2
+    noise = np.column_stack([np.zeros(B), rs.uniform(0.5, 2.0, B), np.full(B, 0.9), rs.uniform(0.5, 2.0, B)])
+    dev = torch.device('cuda')
+    t_out, t_yobs, t_noise, t_aux = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (out, yobs, noise, Rinv.ravel()))
+    desc = (_lib.LikeTarget * 2)(_lib.LikeTarget(n1, 0, _lib.COV_EXP, 0, 0.0), _lib.LikeTarget(n2, n1, _lib.COV_GAUSS, 0, 1.5))
+    need = lib.bh_likelihood_workspace_bytes(B, 2, desc)
+    res = []
+    for stages in ((3,), (1, 2)):
+        ws = torch.full((need // 8,), float('nan'), dtype=torch.float64, device=dev)
+        logL = torch.zeros(B, dtype=torch.float64, device=dev)
+        mis = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+        for st in stages:
+            _lib.check(lib.bh_likelihood_stage(st, B, 2, desc, t_out.data_ptr(), n1 + n2, None, 0, t_yobs.data_ptr(),
+                                               t_noise.data_ptr(), t_aux.data_ptr(), logL.data_ptr(), mis.data_ptr(),
+                                               ws.data_ptr(), need, None))
+        torch.cuda.synchronize()
+        res.append((logL.cpu().numpy(), mis.cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.isfinite(res[0][0]).all()
+    logL = torch.zeros(B, dtype=torch.float64, device=dev)
+    mis = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    for bad in (0, 4):
+        assert lib.bh_likelihood_stage(bad, B, 2, desc, t_out.data_ptr(), n1 + n2, None, 0, t_yobs.data_ptr(), t_noise.data_ptr(),
+                                       t_aux.data_ptr(), logL.data_ptr(), mis.data_ptr(), None, 0, None) != 0
+    assert lib.bh_likelihood_stage(1, B, 2, desc, t_out.data_ptr(), n1 + n2, None, 0, t_yobs.data_ptr(), t_noise.data_ptr(),
+                                   t_aux.data_ptr(), logL.data_ptr(), mis.data_ptr(), None, 0, None) != 0
