@@ -337,3 +337,18 @@ def test_rf_only_plan_flags_bad_depths_like_the_engine():
     bad = np.zeros(64, dtype=bool)
     bad[[3, 17, 40]] = True
     assert np.all(logL[bad] == -1e15) and np.all(np.isfinite(logL[~bad])) and np.all(logL[~bad] > -1e15)
+
+
+def test_plans_made_used_and_closed_by_several_threads_at_once():
+    """Four host threads, each making, using and closing twelve evaluation plans while the others launch, on a ring of
+    8 work-queue slots (tests/scenarios/thread_stress.py; a child process): slots are claimed across threads, and a
+    plan's streams are retired while other threads hold slots whose guard events were recorded on them -- the case
+    retire_stream waits for (capi.hip).  Every one of the 288 batches returns the first batch's bits."""
+    import json
+    import subprocess
+    env = dict(os.environ, BH_SWD_QUEUE_SLOTS='8')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'scenarios', 'thread_stress.py'), '4', '12', '6'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['ok'] and rec['batches'] == 4 * 12 * 6 and rec['slots'] == '8'
