@@ -149,6 +149,11 @@ _SIGS = {
     "bh_chains_accepted": (C.c_int, [_vp, _vp]),
     "bh_chains_done": (C.c_int, [_vp]),
     "bh_chains_iteration": (C.c_long, [_vp]),
+    "bh_chains_set_lookahead": (C.c_int, [_vp, C.c_int]),
+    "bh_chains_lookahead": (C.c_int, [_vp]),
+    "bh_chains_rows": (C.c_long, [_vp]),
+    "bh_chains_advance": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "bh_chains_iterations": (C.c_int, [_vp, _vp]),
     "bh_chains_counters": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "bh_chains_current": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), _vp, _vp, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), _vp]),

@@ -37,6 +37,10 @@ DEFAULT_INITPARAMS = dict(nchains=3, iter_burnin=2048 * 2, iter_main=2048, propd
                           station='test', savepath='results/', maxmodels=50000)
 
 
+LOOKAHEAD_MAX = 512       # BH_CHAIN_MAX_LOOKAHEAD
+LOOKAHEAD_ROWS = 2048     # models per device call the default look-ahead aims at (profiles/r04_lookahead_sweep.txt)
+
+
 def _is_number(x):
     return isinstance(x, (int, float, np.floating, np.integer))
 
@@ -118,7 +122,7 @@ class GpuEvaluator(object):
 class _Group(object):
     """A contiguous range of chains behind one bh_chain_pool handle."""
 
-    def __init__(self, lib, cfg, seeds, arrays, first, last, Lmax, evaluator, ntargets):
+    def __init__(self, lib, cfg, seeds, arrays, first, last, Lmax, evaluator, ntargets, lookahead=1):
         self.lib, self.first, self.last = lib, first, last
         n = last - first
         self.n, self.Lmax = n, Lmax
@@ -134,7 +138,10 @@ class _Group(object):
         self.seeds = np.ascontiguousarray(seeds[first:last], dtype=np.uint32)
         self.handle = C.c_void_p()
         _lib.check(lib.bh_chains_create(C.byref(cfg), n, self.seeds.ctypes.data, C.byref(st), C.byref(self.handle)))
-        self.packed, self.nlay, self.noise, self.chain = evaluator.buffers(n, Lmax, ntargets)
+        if lookahead != 1:
+            _lib.check(lib.bh_chains_set_lookahead(self.handle, int(lookahead)))
+        self.lookahead = int(lookahead)
+        self.packed, self.nlay, self.noise, self.chain = evaluator.buffers(n * self.lookahead, Lmax, ntargets)
         self.count = 0
         self.ticket = None
 
@@ -184,6 +191,12 @@ class ChainPool(object):
                  int(iterations * max(acceptance) / 100) (src/mcmcOptimizer.py:87-89) -- a chain that
                  accepts more than that overflows (IndexError there, an error from bh_chains_accept
                  here), which short runs do easily; `iterations + 1` can never overflow.
+    lookahead    proposals per chain and device call (1 .. 64; bh_chains_set_lookahead): with more than one, a
+                 chain also hands in the proposals of its following iterations for the likeliest outcomes of
+                 the ones before and advances by as many iterations as the likelihoods confirm -- the same
+                 samples in fewer, larger device calls.  Default: enough to give a call of a group about
+                 LOOKAHEAD_ROWS models when the evaluator is the GPU's (small pools are bound by the latency
+                 of a call, not by its size), 1 for any other evaluator.
     shard        (rank, world): this process runs only its contiguous block of the nchains chains
                  (distributed.shard_range), one process per GPU.  Seeds are drawn for ALL chains
                  first, so chain c is the same chain whatever the number of ranks; chains never
@@ -197,7 +210,7 @@ class ChainPool(object):
     """
 
     def __init__(self, targets, initparams=None, modelpriors=None, random_seed=None, nchains=None,
-                 seeds=None, evaluator=None, groups=None, nthreads=None, shard=None, nmodels=None):
+                 seeds=None, evaluator=None, groups=None, nthreads=None, shard=None, nmodels=None, lookahead=None):
         self.lib = _lib.load()
         self.targets = targets
         self.priors = dict(DEFAULT_PRIORS)
@@ -257,8 +270,15 @@ class ChainPool(object):
             groups = 2 if self.nchains >= 512 else 1
         groups = max(1, min(int(groups), self.nchains))
         bounds = [(g * self.nchains) // groups for g in range(groups + 1)]
+        if lookahead is None:
+            per_group = max(1, self.nchains // groups)
+            lookahead = max(2 if per_group <= LOOKAHEAD_ROWS else 1, min(LOOKAHEAD_MAX, LOOKAHEAD_ROWS // per_group)) \
+                if isinstance(evaluator, GpuEvaluator) else 1
+        self.lookahead = int(lookahead)
+        if not 1 <= self.lookahead <= LOOKAHEAD_MAX:
+            raise ValueError("lookahead: 1 .. %d proposals per chain and call" % LOOKAHEAD_MAX)
         self.groups = [_Group(self.lib, self.cfg, self.seeds, arrays, bounds[g], bounds[g + 1], self.Lmax,
-                              evaluator, self.ntargets) for g in range(groups)]
+                              evaluator, self.ntargets, self.lookahead) for g in range(groups)]
         if hasattr(evaluator, 'set_concurrency'):          # the groups' batches alternate on the device
             evaluator.set_concurrency(len(self.groups))
         if nthreads is not None:
@@ -270,12 +290,14 @@ class ChainPool(object):
         self.seconds = dict(propose=0.0, submit=0.0, wait=0.0, accept=0.0)
         self._finished = False
         self._closed_counters = None
+        self._closed_advance = None
 
     def close(self):
         """Release the pool's native resources (idempotent); results stay readable."""
         groups = getattr(self, 'groups', ())
         if self._closed_counters is None and groups and all(g.handle for g in groups):
             self._closed_counters = self.counters()
+            self._closed_advance = self.advance()
         for g in groups:
             g.close(getattr(self, 'evaluator', None))
 
@@ -380,7 +402,20 @@ class ChainPool(object):
 
     @property
     def iteration(self):
+        """The iteration every chain has reached (with a look-ahead chains advance at their own pace)."""
         return min(self.lib.bh_chains_iteration(g.handle) for g in self.groups)
+
+    def advance(self):
+        """(device calls, chain iterations completed, models evaluated) of the iterations so far, initial models
+        not counted; iterations / calls / nchains-per-group is what a call advances a chain by on average."""
+        if self._closed_advance is not None and self.closed:
+            return self._closed_advance
+        tot = [0, 0, 0]
+        for g in self.groups:
+            v = [C.c_long(0) for _ in range(3)]
+            _lib.check(self.lib.bh_chains_advance(g.handle, *[C.byref(x) for x in v]))
+            tot = [a + x.value for a, x in zip(tot, v)]
+        return tuple(tot)
 
     # -- results -----------------------------------------------------------------------------
     def counters(self):

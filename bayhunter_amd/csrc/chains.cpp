@@ -152,17 +152,34 @@ struct Span {
     const double &operator[](long i) const { return p[i]; }
 };
 
+// One node of a chain's look-ahead tree: a proposal, the iteration it belongs to and where it hangs.
+// With a look-ahead of one node per chain (the default) the tree is its root: the proposal of the chain's
+// next iteration.
+struct Proposal {
+    int pn, move, valid, slot, took;     // took: the walk over the results made this proposal the current model
+    int parent, src, child[2];           // src: the node whose proposal is the current model here (-1: the chain's);
+                                         // child[0]: next iteration if this one is rejected (or invalid), [1]: accepted
+    long iter;
+    Span pvs, pz;
+    double pnoise[MAXN], pvpvs, dvs2, logu, prob;
+};
+
+struct Current {                         // the model a proposal starts from
+    int n;
+    const double *vs, *z, *noise;
+    double vpvs;
+};
+
 struct Chain {
     Rng rng;
     int n;                                   // nuclei of the current model
     Span vs, z;
     double noise[MAXN], vpvs, like, misfits[BH_MAX_TARGETS + 1];
     double propdist[5], accepted[5], proposed[5];
-    long nstored, lastmoditer;
-    // proposal of the running iteration
-    int pn, move, valid, slot, took;     // took: the last accept replaced the current model by the proposal
-    Span pvs, pz;
-    double pnoise[MAXN], pvpvs, dvs2;
+    long nstored, lastmoditer, iter;         // iter: the next iteration of this chain
+    int nnodes;                              // proposals of the running call
+    Proposal *nodes;                         // [lookahead]
+    Rng *after;                              // [lookahead]: the stream behind each node's draws (NULL: one node, rng itself)
 };
 
 // Persistent helper threads: propose/accept run once per iteration over a few thousand chains, too
@@ -287,13 +304,19 @@ struct bh_chain_pool {
     bh_chain_config cfg;
     bh_chain_storage st;
     int nchains, maxl, nthreads;
-    long iiter, iterations;
+    long iiter, iterations;                  // iiter: the iteration every chain has reached (the slowest chain's next)
     int stage;                               // 0: initial models next, 1: their results awaited,
                                              // 2: proposals next, 3: their results awaited
     int count, failed;
+    int lookahead;                           // proposals per chain and call (nodes of its look-ahead tree)
+    long calls, advanced, rows;              // propose/accept pairs after the initial one, chain iterations they
+                                             // completed, models they handed out
     std::vector<int> noiseinds;
     std::vector<Chain> chains;
-    std::vector<double> arena;
+    std::vector<double> arena, node_arena;
+    std::vector<Proposal> nodes;
+    std::vector<Rng> snaps;
+    std::vector<int> first_slot;
 };
 
 namespace {
@@ -301,8 +324,7 @@ namespace {
 void for_chains(bh_chain_pool *p, const std::function<void(int)> &f)
 {
     // One set of helper threads for the whole process: the groups of a ChainPool take turns on the
-    // host, and two sets of spinning workers would fight for the same cores.  A block of fewer than
-    // ~128 chains is not worth a thread.
+    // host, and two sets of spinning workers would fight for the same cores.
     // The set lives on the heap and is never destroyed; after a fork() (the broker forks chain
     // processes) the child has none of the parent's threads and starts a set of its own.
     static Workers *workers = nullptr;
@@ -313,7 +335,8 @@ void for_chains(bh_chain_pool *p, const std::function<void(int)> &f)
         workers = new Workers();
         owner = getpid();
     }
-    workers->run(p->nchains, std::max(1, std::min(p->nthreads, p->nchains / 128)), f);
+    // (a block of fewer than ~128 proposals is not worth a thread)
+    workers->run(p->nchains, std::max(1, std::min(std::min(p->nthreads, p->nchains), p->nchains * p->lookahead / 128)), f);
 }
 
 // Model.get_vp_vs_h: interfaces midway between neighbouring nuclei, half space h = 0
@@ -391,24 +414,24 @@ int nearest(int n, const double *z, double z0)
     return best;
 }
 
-void initial_model(bh_chain_pool *p, Chain &c)
+void initial_model(const bh_chain_pool *p, Rng &rng, Proposal &c)
 {
     const bh_chain_config &g = p->cfg;
     // draw_initvpvs
-    c.pvpvs = g.vpvs_fixed ? g.vpvs_min : c.rng.uniform(g.vpvs_min, g.vpvs_max);
+    c.pvpvs = g.vpvs_fixed ? g.vpvs_min : rng.uniform(g.vpvs_min, g.vpvs_max);
     // draw_initmodel: the minimum number of layers, redrawn until the priors hold
     int n = g.layers_min + 1;
     for (;;) {
-        for (int i = 0; i < n; i++) c.pvs[i] = c.rng.uniform(g.vs_min, g.vs_max);
+        for (int i = 0; i < n; i++) c.pvs[i] = rng.uniform(g.vs_min, g.vs_max);
         std::sort(c.pvs.data(), c.pvs.data() + n);
         if (g.has_mohoest && n > 1) {
-            double moho = c.rng.normal(g.moho_mean, g.moho_std);
-            double half = c.rng.uniform(1, std::min(5.0, moho));
+            double moho = rng.normal(g.moho_mean, g.moho_std);
+            double half = rng.uniform(1, std::min(5.0, moho));
             c.pz[0] = moho - half;
             c.pz[1] = moho + half;
-            for (int i = 2; i < n; i++) c.pz[i] = c.rng.uniform(g.z_min, g.z_max);
+            for (int i = 2; i < n; i++) c.pz[i] = rng.uniform(g.z_min, g.z_max);
         } else {
-            for (int i = 0; i < n; i++) c.pz[i] = c.rng.uniform(g.z_min, g.z_max);
+            for (int i = 0; i < n; i++) c.pz[i] = rng.uniform(g.z_min, g.z_max);
         }
         std::sort(c.pz.data(), c.pz.data() + n);
         if (valid_model(g, n, c.pvs.data(), c.pz.data())) break;
@@ -416,45 +439,47 @@ void initial_model(bh_chain_pool *p, Chain &c)
     c.pn = n;
     // draw_initnoiseparams
     for (int i = 0; i < 2 * g.ntargets; i++)
-        c.pnoise[i] = g.noise_fixed[i] ? g.noise_lo[i] : c.rng.uniform(g.noise_lo[i], g.noise_hi[i]);
+        c.pnoise[i] = g.noise_fixed[i] ? g.noise_lo[i] : rng.uniform(g.noise_lo[i], g.noise_hi[i]);
     c.valid = 1;
     c.move = -1;
 }
 
-void propose(bh_chain_pool *p, Chain &c)
+// The proposal of iteration `iter` for a chain whose current model is `cur` and whose random stream stands at
+// `rng` (SingleChain.iterate up to the forward call, :511-552)
+void propose(const bh_chain_pool *p, long iter, Rng &rng, const Current &cur, const double *propdist, Proposal &c)
 {
     const bh_chain_config &g = p->cfg;
     const int nnoise = p->noiseinds.empty() ? 0 : 1, nvpvs = g.vpvs_fixed ? 0 : 1;
     // only vs and depth moves (and the hyper-parameters) during the first 1 % of the iterations
-    bool early = (double)p->iiter < (double)(-g.iter_burnin) + (double)p->iterations * 0.01;
-    int k = (int)c.rng.randint(0, (early ? 2 : 4) + nnoise + nvpvs);
+    bool early = (double)iter < (double)(-g.iter_burnin) + (double)p->iterations * 0.01;
+    int k = (int)rng.randint(0, (early ? 2 : 4) + nnoise + nvpvs);
     int nmodel = early ? 2 : 4;
     int move = k < nmodel ? k : (k - nmodel < nnoise ? NOISE : VPVS);
     c.move = move;
-    int n = c.n;
-    std::memcpy(c.pvs.data(), c.vs.data(), n * sizeof(double));
-    std::memcpy(c.pz.data(), c.z.data(), n * sizeof(double));
-    std::memcpy(c.pnoise, c.noise, 2 * g.ntargets * sizeof(double));
-    c.pvpvs = c.vpvs;
+    int n = cur.n;
+    std::memcpy(c.pvs.data(), cur.vs, n * sizeof(double));
+    std::memcpy(c.pz.data(), cur.z, n * sizeof(double));
+    std::memcpy(c.pnoise, cur.noise, 2 * g.ntargets * sizeof(double));
+    c.pvpvs = cur.vpvs;
     c.pn = n;
     c.valid = 1;
     switch (move) {
     case VSMOD: {
-        long i = c.rng.randint(0, n);
-        double step = c.rng.normal(0, c.propdist[0]);
+        long i = rng.randint(0, n);
+        double step = rng.normal(0, propdist[0]);
         c.pvs[i] = c.pvs[i] + step;
         break;
     }
     case ZVMOD: {
-        long i = c.rng.randint(n, 2 * n) - n;
-        double step = c.rng.normal(0, c.propdist[1]);
+        long i = rng.randint(n, 2 * n) - n;
+        double step = rng.normal(0, propdist[1]);
         c.pz[i] = c.pz[i] + step;
         break;
     }
     case BIRTH: {
-        double zb = c.rng.uniform(g.z_min, g.z_max);
-        double before = c.vs[nearest(n, c.z.data(), zb)];
-        double vb = before + c.rng.normal(0, c.propdist[2]);
+        double zb = rng.uniform(g.z_min, g.z_max);
+        double before = cur.vs[nearest(n, cur.z, zb)];
+        double vb = before + rng.normal(0, propdist[2]);
         c.pz[n] = zb;
         c.pvs[n] = vb;
         c.pn = n + 1;
@@ -463,8 +488,8 @@ void propose(bh_chain_pool *p, Chain &c)
         break;
     }
     case DEATH: {
-        long gone = c.rng.randint(0, n);
-        double zg = c.z[gone], vg = c.vs[gone];
+        long gone = rng.randint(0, n);
+        double zg = cur.z[gone], vg = cur.vs[gone];
         for (int i = (int)gone; i + 1 < n; i++) { c.pvs[i] = c.pvs[i + 1]; c.pz[i] = c.pz[i + 1]; }
         c.pn = n - 1;
         if (c.pn < 1) { c.valid = 0; break; }     // the reference cannot remove the last nucleus
@@ -473,15 +498,15 @@ void propose(bh_chain_pool *p, Chain &c)
         break;
     }
     case NOISE: {
-        int i = p->noiseinds[c.rng.randint(0, (long)p->noiseinds.size())];
-        double step = c.rng.normal(0, c.propdist[3]);
+        int i = p->noiseinds[rng.randint(0, (long)p->noiseinds.size())];
+        double step = rng.normal(0, propdist[3]);
         c.pnoise[i] = c.pnoise[i] + step;
         for (int j : p->noiseinds)
             if (c.pnoise[j] < g.noise_lo[j] || c.pnoise[j] > g.noise_hi[j]) c.valid = 0;
         return;
     }
     case VPVS: {
-        double step = c.rng.normal(0, c.propdist[4]);
+        double step = rng.normal(0, propdist[4]);
         c.pvpvs = c.pvpvs + step;
         if (c.pvpvs < g.vpvs_min || c.pvpvs > g.vpvs_max) c.valid = 0;
         return;
@@ -492,7 +517,7 @@ void propose(bh_chain_pool *p, Chain &c)
     c.valid = valid_model(g, c.pn, c.pvs.data(), c.pz.data()) ? 1 : 0;
 }
 
-bool store(bh_chain_pool *p, int ci, Chain &c)
+bool store(bh_chain_pool *p, int ci, Chain &c, long iter)
 {
     const bh_chain_storage &s = p->st;
     if (c.nstored >= s.nmodels) return false;
@@ -504,22 +529,22 @@ bool store(bh_chain_pool *p, int ci, Chain &c)
     s.likes[row] = (float)c.like;
     for (int i = 0; i < 2 * T; i++) s.noise[row * 2 * T + i] = (float)c.noise[i];
     s.vpvs[row] = (float)c.vpvs;
-    s.iter[row] = (double)p->iiter;
+    s.iter[row] = (double)iter;
     c.nstored++;
     return true;
 }
 
-void take_proposal(bh_chain_pool *p, Chain &c, const double *logL, const double *misfits)
+void take_proposal(bh_chain_pool *p, Chain &c, const Proposal &q, const double *logL, const double *misfits)
 {
     const int T = p->cfg.ntargets;
-    c.like = logL[c.slot];
-    std::memcpy(c.misfits, misfits + (long)c.slot * (T + 1), (T + 1) * sizeof(double));
-    c.n = c.pn;
-    std::memcpy(c.vs.data(), c.pvs.data(), c.pn * sizeof(double));
-    std::memcpy(c.z.data(), c.pz.data(), c.pn * sizeof(double));
-    std::memcpy(c.noise, c.pnoise, 2 * T * sizeof(double));
-    c.vpvs = c.pvpvs;
-    c.lastmoditer = p->iiter;
+    c.like = logL[q.slot];
+    std::memcpy(c.misfits, misfits + (long)q.slot * (T + 1), (T + 1) * sizeof(double));
+    c.n = q.pn;
+    std::memcpy(c.vs.data(), q.pvs.data(), q.pn * sizeof(double));
+    std::memcpy(c.z.data(), q.pz.data(), q.pn * sizeof(double));
+    std::memcpy(c.noise, q.pnoise, 2 * T * sizeof(double));
+    c.vpvs = q.pvpvs;
+    c.lastmoditer = q.iter;
 }
 
 void adjust_propdist(const bh_chain_config &g, Chain &c)
@@ -537,35 +562,151 @@ void adjust_propdist(const bh_chain_config &g, Chain &c)
     }
 }
 
-bool decide(bh_chain_pool *p, int ci, Chain &c, const double *logL, const double *misfits)
+bool adjusts(long iter) { return ((iter % 1000) + 1000) % 1000 == 0; }
+
+Current current_of(const Chain &c, int src)
+{
+    if (src < 0) return Current{c.n, c.vs.data(), c.z.data(), c.noise, c.vpvs};
+    const Proposal &q = c.nodes[src];
+    return Current{q.pn, q.pvs.data(), q.pz.data(), q.pnoise, q.pvpvs};
+}
+
+// Look-ahead ("prefetching", Brockwell 2006): the proposal of the chain's next iteration and, when the pool
+// evaluates more than one model per chain and call, the proposals of the iterations after it for the outcomes
+// that are most likely -- a tree whose node (k rejections, m acceptances down from the root) is what
+// SingleChain.iterate would propose after exactly those outcomes.  Nothing about an outcome is needed to draw a
+// proposal except the current model: the stream position after an iteration is the same whether it was accepted
+// or not (one `uniform` after the forward call, :554), and the proposal widths change only every 1000th iteration
+// (:578) -- the tree never grows past one of those.  When the likelihoods are back the chain walks the tree from
+// its root, deciding each iteration exactly as the reference does, for as far as the tree has the node of the
+// outcome: the chain advances by the length of that walk (>= 1), the other nodes were evaluated for nothing.  The
+// samples are those of the one-iteration-per-call chain, draw for draw.
+struct Edge {
+    double prob;
+    int node, outcome;
+    bool operator<(const Edge &o) const { return prob < o.prob; }
+};
+
+void grow(const bh_chain_pool *p, Chain &c)
+{
+    const bh_chain_config &g = p->cfg;
+    c.nnodes = 0;
+    if (c.iter >= g.iter_main) return;
+    auto fresh = [&](int y, int parent, int src, long iter, double prob) -> Proposal & {
+        Proposal &q = c.nodes[y];
+        q.parent = parent; q.src = src; q.iter = iter; q.prob = prob;
+        q.child[0] = q.child[1] = -1;
+        q.slot = -1; q.took = 0; q.logu = 0.0; q.dvs2 = 0.0;
+        return q;
+    };
+    Proposal &root = fresh(0, -1, -1, c.iter, 1.0);
+    propose(p, c.iter, c.rng, current_of(c, -1), c.propdist, root);
+    if (root.valid) root.logu = std::log(c.rng.uniform(0, 1));
+    c.nnodes = 1;
+    const int N = p->lookahead;
+    if (N == 1) return;
+    c.after[0] = c.rng;
+    Edge heap[2 * BH_CHAIN_MAX_LOOKAHEAD + 2];
+    int nheap = 0;
+    auto offer = [&](int x) {
+        const Proposal &q = c.nodes[x];
+        if (q.iter + 1 >= g.iter_main || (q.valid && adjusts(q.iter))) return;
+        double a = 0.0;
+        if (q.valid) {
+            // the expected outcome: the chain's own acceptance rate for this kind of move so far.  (Rates of the last
+            // ~32 outcomes per move, or per move and size class of the step, predict no better: 6.6 iterations per
+            // call of 32 proposals either way on the tutorial inversion -- whether a step goes uphill is the coin.)
+            int par = PAR_OF_MOVE[q.move];
+            a = (c.accepted[par] + 1.) / (c.proposed[par] + 3.);
+            heap[nheap++] = Edge{q.prob * a, x, 1};
+            std::push_heap(heap, heap + nheap);
+        }
+        heap[nheap++] = Edge{q.prob * (1. - a), x, 0};
+        std::push_heap(heap, heap + nheap);
+    };
+    offer(0);
+    while (c.nnodes < N && nheap > 0) {
+        std::pop_heap(heap, heap + nheap);
+        Edge e = heap[--nheap];
+        int y = c.nnodes++;
+        Proposal &q = fresh(y, e.node, e.outcome ? e.node : c.nodes[e.node].src, c.nodes[e.node].iter + 1, e.prob);
+        c.nodes[e.node].child[e.outcome] = y;
+        Rng &rng = c.after[y];
+        rng = c.after[e.node];
+        propose(p, q.iter, rng, current_of(c, q.src), c.propdist, q);
+        if (q.valid) q.logu = std::log(rng.uniform(0, 1));
+        offer(y);
+    }
+}
+
+// The decisions of the iterations the tree covers (SingleChain.iterate from :554 on), root first
+bool walk(bh_chain_pool *p, int ci, Chain &c, const double *logL, const double *misfits)
 {
     const bh_chain_config &g = p->cfg;
     bool ok = true;
-    c.took = 0;
-    if (!c.valid) return true;                      // iterate() returned before anything else
-    int par = PAR_OF_MOVE[c.move];
-    c.proposed[par] += 1;
-    double u = std::log(c.rng.uniform(0, 1));
-    double ratio = logL[c.slot] - c.like, alpha = ratio;
-    if (c.move == BIRTH || c.move == DEATH) {
-        double theta = c.propdist[2], dv = g.vs_max - g.vs_min;
-        double B = c.dvs2 / (2. * (theta * theta));
-        if (c.move == BIRTH) {
-            double A = (theta * std::sqrt(2 * M_PI)) / dv;
-            alpha = std::log(A) + B + ratio;
-        } else {
-            double A = dv / (theta * std::sqrt(2 * M_PI));
-            alpha = std::log(A) - B + ratio;
+    int x = 0;
+    while (c.nnodes > 0) {
+        Proposal &q = c.nodes[x];
+        int outcome = 0;
+        if (q.valid) {                                  // (otherwise iterate() returned before anything else)
+            int par = PAR_OF_MOVE[q.move];
+            c.proposed[par] += 1;
+            double ratio = logL[q.slot] - c.like, alpha = ratio;
+            if (q.move == BIRTH || q.move == DEATH) {
+                double theta = c.propdist[2], dv = g.vs_max - g.vs_min;
+                double B = q.dvs2 / (2. * (theta * theta));
+                if (q.move == BIRTH) {
+                    double A = (theta * std::sqrt(2 * M_PI)) / dv;
+                    alpha = std::log(A) + B + ratio;
+                } else {
+                    double A = dv / (theta * std::sqrt(2 * M_PI));
+                    alpha = std::log(A) - B + ratio;
+                }
+            }
+            if (q.logu < alpha) {
+                outcome = 1;
+                q.took = 1;
+                take_proposal(p, c, q, logL, misfits);
+                if (!store(p, ci, c, q.iter)) ok = false;
+                c.accepted[par] += 1;
+            }
+            if (adjusts(q.iter)) adjust_propdist(g, c);
+        }
+        c.iter = q.iter + 1;
+        int next = ok ? q.child[outcome] : -1;
+        if (next < 0) {
+            if (c.after) c.rng = c.after[x];
+            break;
+        }
+        x = next;
+    }
+    return ok;
+}
+
+void point_nodes(bh_chain_pool *p)
+{
+    const long W = p->maxl + 2;
+    const int N = p->lookahead;
+    p->nodes.assign((size_t)p->nchains * N, Proposal());
+    p->node_arena.assign((size_t)p->nchains * N * 2 * W, 0.0);
+    p->snaps.clear();
+    p->snaps.shrink_to_fit();
+    if (N > 1) p->snaps.resize((size_t)p->nchains * N);
+    for (int i = 0; i < p->nchains; i++) {
+        Chain &c = p->chains[i];
+        c.nodes = p->nodes.data() + (size_t)i * N;
+        c.after = N > 1 ? p->snaps.data() + (size_t)i * N : nullptr;
+        c.nnodes = 0;
+        for (int k = 0; k < N; k++) {
+            Proposal &q = c.nodes[k];
+            double *a = p->node_arena.data() + ((size_t)i * N + k) * 2 * W;
+            q.pvs.p = a; q.pz.p = a + W;
+            std::memset(q.pnoise, 0, sizeof(q.pnoise));
+            q.pn = 0; q.move = -1; q.valid = 0; q.slot = -1; q.took = 0;
+            q.parent = q.src = q.child[0] = q.child[1] = -1;
+            q.iter = 0; q.pvpvs = q.dvs2 = q.logu = q.prob = 0.0;
         }
     }
-    if (u < alpha) {
-        c.took = 1;
-        take_proposal(p, c, logL, misfits);
-        ok = store(p, ci, c);
-        c.accepted[par] += 1;
-    }
-    if (((p->iiter % 1000) + 1000) % 1000 == 0) adjust_propdist(g, c);
-    return ok;
 }
 
 }  // namespace
@@ -594,24 +735,28 @@ int bh_chains_create(const bh_chain_config *cfg, int nchains, const unsigned *se
     p->stage = 0;
     p->count = 0;
     p->failed = 0;
+    p->lookahead = 1;
+    p->calls = p->advanced = p->rows = 0;
     for (int i = 0; i < 2 * cfg->ntargets; i++)
         if (!cfg->noise_fixed[i]) p->noiseinds.push_back(i);
     p->chains.resize(nchains);
     const long W = p->maxl + 2;
-    p->arena.assign((size_t)nchains * 4 * W, 0.0);
+    p->arena.assign((size_t)nchains * 2 * W, 0.0);
+    p->first_slot.assign(nchains + 1, 0);
     for (int i = 0; i < nchains; i++) {
         Chain &c = p->chains[i];
         c.rng.seed(seeds[i]);
         c.n = 0;
-        double *a = p->arena.data() + (size_t)i * 4 * W;
-        c.vs.p = a; c.z.p = a + W; c.pvs.p = a + 2 * W; c.pz.p = a + 3 * W;
-        std::memset(c.noise, 0, sizeof(c.noise)); std::memset(c.pnoise, 0, sizeof(c.pnoise));
+        double *a = p->arena.data() + (size_t)i * 2 * W;
+        c.vs.p = a; c.z.p = a + W;
+        std::memset(c.noise, 0, sizeof(c.noise));
         std::memset(c.misfits, 0, sizeof(c.misfits));
-        c.vpvs = c.pvpvs = 0.0; c.like = 0.0; c.dvs2 = 0.0;
+        c.vpvs = 0.0; c.like = 0.0;
         for (int k = 0; k < 5; k++) { c.propdist[k] = cfg->propdist[k]; c.accepted[k] = c.proposed[k] = 0.0; }
-        c.nstored = 0; c.lastmoditer = p->iiter;
-        c.pn = 0; c.move = -1; c.valid = 0; c.slot = -1; c.took = 0;
+        c.nstored = 0; c.lastmoditer = p->iiter; c.iter = p->iiter;
+
     }
+    point_nodes(p);
     // start the helper threads now rather than inside the first timed iteration (creating 15 threads
     // in a process that has the GPU's address ranges mapped costs ~0.1 s on a GPU box)
     for_chains(p, [](int) {});
@@ -629,6 +774,30 @@ int bh_chains_set_threads(bh_chain_pool *p, int n)
     return BH_OK;
 }
 
+int bh_chains_set_lookahead(bh_chain_pool *p, int nodes)
+{
+    if (!p || nodes < 1 || nodes > BH_CHAIN_MAX_LOOKAHEAD)
+        return bh::fail_arg_("bh_chains_set_lookahead: 1 .. BH_CHAIN_MAX_LOOKAHEAD proposals per chain");
+    if (p->stage != 0 && p->stage != 2) return bh::fail_arg_("bh_chains_set_lookahead: results of the last proposals are still due");
+    if (nodes == p->lookahead) return BH_OK;
+    p->lookahead = nodes;
+    point_nodes(p);
+    for_chains(p, [](int) {});
+    return BH_OK;
+}
+
+int bh_chains_lookahead(const bh_chain_pool *p) { return p ? p->lookahead : 0; }
+long bh_chains_rows(const bh_chain_pool *p) { return p ? (long)p->nchains * p->lookahead : 0; }
+
+int bh_chains_advance(const bh_chain_pool *p, long *calls, long *iterations, long *rows)
+{
+    if (!p) return bh::fail_arg_("bh_chains_advance: NULL pool");
+    if (calls) *calls = p->calls;
+    if (iterations) *iterations = p->advanced;
+    if (rows) *rows = p->rows;
+    return BH_OK;
+}
+
 int bh_chains_done(const bh_chain_pool *p) { return (p && p->stage >= 2 && p->iiter >= p->cfg.iter_main) ? 1 : 0; }
 long bh_chains_iteration(const bh_chain_pool *p) { return p ? p->iiter : 0; }
 
@@ -641,27 +810,47 @@ int bh_chains_propose(bh_chain_pool *p, int Lmax, double *packed, int *nlay, dou
     if (Lmax < p->maxl) return bh::fail_arg_("bh_chains_propose: Lmax smaller than layers_max + 1");
     if (p->stage == 2 && p->iiter >= p->cfg.iter_main) { *count = 0; return BH_OK; }
     const bool init = p->stage == 0;
-    for_chains(p, [=](int i) { init ? initial_model(p, p->chains[i]) : propose(p, p->chains[i]); });
-    int k = 0;
-    for (int i = 0; i < p->nchains; i++) {
+    int *first = p->first_slot.data();
+    for_chains(p, [=](int i) {
         Chain &c = p->chains[i];
-        c.slot = c.valid ? k : -1;
-        if (c.valid) chain[k++] = i;
-    }
+        if (init) {
+            Proposal &q = c.nodes[0];
+            q.parent = q.src = q.child[0] = q.child[1] = -1;
+            q.iter = c.iter; q.prob = 1.0; q.took = 0; q.slot = -1; q.logu = q.dvs2 = 0.0;
+            initial_model(p, c.rng, q);
+            if (c.after) c.after[0] = c.rng;
+            c.nnodes = 1;
+        } else {
+            grow(p, c);
+        }
+        int valid = 0;
+        for (int k = 0; k < c.nnodes; k++) valid += c.nodes[k].valid ? 1 : 0;
+        first[i + 1] = valid;
+    });
+    first[0] = 0;
+    for (int i = 0; i < p->nchains; i++) first[i + 1] += first[i];
     const int T2 = 2 * p->cfg.ntargets;
     for_chains(p, [=](int i) {
         Chain &c = p->chains[i];
-        if (!c.valid) return;
-        double *row = packed + (long)c.slot * 4 * Lmax;
-        std::memset(row, 0, 4 * Lmax * sizeof(double));
-        double *h = row, *vp = row + Lmax, *vs = row + 2 * Lmax, *rho = row + 3 * Lmax;
-        layers_of(p->cfg, c.pn, c.pvs.data(), c.pz.data(), c.pvpvs, h, vp);
-        for (int l = 0; l < c.pn; l++) { vs[l] = c.pvs[l]; rho[l] = vp[l] * 0.32 + 0.77; }
-        nlay[c.slot] = c.pn;
-        std::memcpy(noise + (long)c.slot * T2, c.pnoise, T2 * sizeof(double));
+        int k = first[i];
+        for (int x = 0; x < c.nnodes; x++) {
+            Proposal &q = c.nodes[x];
+            q.slot = -1;
+            if (!q.valid) continue;
+            q.slot = k++;
+            chain[q.slot] = i;
+            double *row = packed + (long)q.slot * 4 * Lmax;
+            std::memset(row, 0, 4 * Lmax * sizeof(double));
+            double *h = row, *vp = row + Lmax, *vs = row + 2 * Lmax, *rho = row + 3 * Lmax;
+            layers_of(p->cfg, q.pn, q.pvs.data(), q.pz.data(), q.pvpvs, h, vp);
+            for (int l = 0; l < q.pn; l++) { vs[l] = q.pvs[l]; rho[l] = vp[l] * 0.32 + 0.77; }
+            nlay[q.slot] = q.pn;
+            std::memcpy(noise + (long)q.slot * T2, q.pnoise, T2 * sizeof(double));
+        }
     });
-    p->count = k;
-    *count = k;
+    p->count = first[p->nchains];
+    *count = p->count;
+    if (!init) { p->calls += 1; p->rows += p->count; }
     p->stage += 1;
     return BH_OK;
 }
@@ -675,14 +864,18 @@ int bh_chains_accept(bh_chain_pool *p, const double *logL, const double *misfits
     if (p->stage == 1) {
         for_chains(p, [=](int i) {
             Chain &c = p->chains[i];
-            take_proposal(p, c, logL, misfits);
-            c.took = 1;
-            if (!store(p, i, c)) badp[i] = 1;
+            Proposal &q = c.nodes[0];
+            take_proposal(p, c, q, logL, misfits);
+            q.took = 1;
+            if (!store(p, i, c, q.iter)) badp[i] = 1;
         });
         p->stage = 2;
     } else {
-        for_chains(p, [=](int i) { if (!decide(p, i, p->chains[i], logL, misfits)) badp[i] = 1; });
-        p->iiter += 1;
+        for_chains(p, [=](int i) { if (!walk(p, i, p->chains[i], logL, misfits)) badp[i] = 1; });
+        long slowest = p->cfg.iter_main, sum = 0;
+        for (const Chain &c : p->chains) { slowest = std::min(slowest, c.iter); sum += c.iter; }
+        p->advanced = sum + (long)p->nchains * p->cfg.iter_burnin;
+        p->iiter = slowest;
         p->stage = 2;
     }
     for (int i = 0; i < p->nchains; i++)
@@ -698,7 +891,8 @@ int bh_chains_moves(const bh_chain_pool *p, int *move)
 {
     if (!p || !move) return bh::fail_arg_("bh_chains_moves: NULL argument");
     for (const Chain &c : p->chains)
-        if (c.valid && c.slot >= 0) move[c.slot] = c.move;
+        for (int k = 0; k < c.nnodes; k++)
+            if (c.nodes[k].slot >= 0) move[c.nodes[k].slot] = c.nodes[k].move;
     return BH_OK;
 }
 
@@ -706,7 +900,15 @@ int bh_chains_accepted(const bh_chain_pool *p, int *flag)
 {
     if (!p || !flag) return bh::fail_arg_("bh_chains_accepted: NULL argument");
     for (const Chain &c : p->chains)
-        if (c.valid && c.slot >= 0) flag[c.slot] = c.took;
+        for (int k = 0; k < c.nnodes; k++)
+            if (c.nodes[k].slot >= 0) flag[c.nodes[k].slot] = c.nodes[k].took;
+    return BH_OK;
+}
+
+int bh_chains_iterations(const bh_chain_pool *p, long *iter)
+{
+    if (!p || !iter) return bh::fail_arg_("bh_chains_iterations: NULL argument");
+    for (int i = 0; i < p->nchains; i++) iter[i] = p->chains[i].iter;
     return BH_OK;
 }
 

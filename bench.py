@@ -306,19 +306,33 @@ def chain_pool_sample(nchains=4096, burnin=100, main_it=50):
     time.sleep(BLAS_SETTLE_S)
     # three samples, the best one reported (all three in the record; since the set-up's BLAS spin is kept out of
     # them -- BLAS_SETTLE_S -- they agree within a few per cent)
-    runs = []
-    for _ in range(3):
-        with ChainPool(joint, initparams=ip, modelpriors=priors, seeds=seeds) as pool:
-            t0 = time.perf_counter()
-            pool.run()
-            torch.cuda.synchronize()
-            runs.append((time.perf_counter() - t0, int(pool.evaluated), dict(pool.seconds)))
-    dt, evaluated, seconds = min(runs, key=lambda r: r[0])
-    return {"ok": True, "value": nchains * (burnin + main_it) / dt, "unit": "chain iterations/s", "nchains": nchains,
-            "iterations": burnin + main_it, "models_evaluated": evaluated,
-            "samples": [round(nchains * (burnin + main_it) / r[0]) for r in runs],
-            "workload": "tutorial joint inversion (rdispph + prf), free vp/vs and noise, 2-21 layers",
-            "host_seconds": {k: round(v, 4) for k, v in seconds.items()}}
+    def sample(n, its_burnin, its_main, repeats, **kw):
+        runs = []
+        par = dict(ip, iter_burnin=its_burnin, iter_main=its_main)
+        for _ in range(repeats):
+            with ChainPool(joint, initparams=par, modelpriors=priors, seeds=seeds[:n], **kw) as pool:
+                t0 = time.perf_counter()
+                pool.run()
+                torch.cuda.synchronize()
+                runs.append((time.perf_counter() - t0, int(pool.evaluated), dict(pool.seconds), pool.lookahead, pool.advance(),
+                             len(pool.groups)))
+        dt, evaluated, seconds, lookahead, (calls, advanced, rows), groups = min(runs, key=lambda r: r[0])
+        its = its_burnin + its_main
+        return {"value": n * its / dt, "unit": "chain iterations/s", "nchains": n, "iterations": its,
+                "models_evaluated": evaluated, "samples": [round(n * its / r[0]) for r in runs],
+                "lookahead": lookahead, "device_calls": calls,
+                "iterations_per_call": round(advanced / max(calls, 1) / (n / groups), 2),
+                "host_seconds": {k: round(v, 4) for k, v in seconds.items()}}
+    rec = sample(nchains, burnin, main_it, 3)
+    rec.update({"ok": True, "workload": "tutorial joint inversion (rdispph + prf), free vp/vs and noise, 2-21 layers"})
+    # the pool size the reference's users run (tutorial: 5 chains; one process per chain there): a call is bound by its
+    # latency, and the pool looks ahead -- several iterations of a chain per call (bh_chains_set_lookahead; same chains)
+    with ChainPool(joint, initparams=dict(ip, iter_burnin=6, iter_main=2), modelpriors=priors, seeds=seeds[:64], nmodels=9) as warm:
+        warm.run()
+    small = sample(64, 400, 200, 2)
+    small["one_proposal_per_call"] = sample(64, 400, 200, 1, lookahead=1)["value"]
+    rec["small_pool"] = small
+    return rec
 
 
 def chain_digest(blocks):
@@ -382,6 +396,7 @@ def sharded_chain_pools(rank, world, ranks, backend, workloads=None, evaluator=N
         pools_rec[name] = {
             "value": total * its / dt, "unit": "chain iterations/s", "chains_per_gpu": wl['chains_per_gpu'],
             "nchains": total, "iterations": its, "seconds": dt, "models_evaluated": int(sum(evaluated)),
+            "lookahead": pool.lookahead, "device_calls_rank0": pool.advance()[0],
             "layers_prior": list(wl['layers']), "sharding": "chains block-partitioned over ranks, no collective while sampling",
             "workload": "tutorial joint inversion (rdispph + prf), free vp/vs and noise, models of 2-%d layers" % (wl['layers'][1] + 1)}
         # -- the exchange: this pool's sample blocks over the process group

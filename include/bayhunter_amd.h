@@ -327,11 +327,12 @@ int  bh_chains_set_threads(bh_chain_pool *pool, int nthreads);
 /* Draw the next proposal of every chain.  Chains whose proposal passed the prior checks are written
  * compacted, k = 0..count-1: packed[k] = h, vp, vs, rho rows of Lmax doubles each (the layout
  * bh_swd_batch takes with model_stride = 4*Lmax; rho = vp*0.32 + 0.77, src/Targets.py:319),
- * nlay[k], noise[k][2*ntargets], chain[k] = the chain it belongs to.  Arrays hold nchains rows. */
+ * nlay[k], noise[k][2*ntargets], chain[k] = the chain it belongs to.  Arrays hold nchains rows
+ * (bh_chains_rows() with a look-ahead, below). */
 int  bh_chains_propose(bh_chain_pool *pool, int Lmax, double *packed, int *nlay, double *noise,
                        int *chain, int *count);
 /* logL[count], misfits[count][ntargets+1] of the models handed out by the last propose: draw u,
- * accept or reject, store, adapt the proposal widths, advance the iteration counter. */
+ * accept or reject, store, adapt the proposal widths, advance the iteration counter(s). */
 int  bh_chains_accept(bh_chain_pool *pool, const double *logL, const double *misfits);
 /* Per model handed out by the last propose (k = 0..count-1): the move that produced it -- 0 vs of a
  * nucleus, 1 depth of a nucleus, 2 birth, 3 death, 4 noise parameter, 5 vp/vs, -1 initial model.
@@ -339,8 +340,26 @@ int  bh_chains_accept(bh_chain_pool *pool, const double *logL, const double *mis
  * the chain's current model. */
 int  bh_chains_moves(const bh_chain_pool *pool, int *move);
 int  bh_chains_accepted(const bh_chain_pool *pool, int *flag);
-int  bh_chains_done(const bh_chain_pool *pool);            /* 1 when iiter reached iter_main  */
-long bh_chains_iteration(const bh_chain_pool *pool);       /* iiter, starts at -iter_burnin   */
+int  bh_chains_done(const bh_chain_pool *pool);            /* 1 when every chain reached iter_main */
+long bh_chains_iteration(const bh_chain_pool *pool);       /* the slowest chain's next iteration; starts at -iter_burnin */
+/* Look-ahead.  A Metropolis chain is sequential -- iteration i+1 starts from the model iteration i leaves
+ * behind (src/SingleChain.py:554-589) -- so a pool of few chains hands the GPU batches far below the size
+ * at which a launch costs more than its latency.  With `nodes` > 1 bh_chains_propose also draws, per chain,
+ * the proposals of the FOLLOWING iterations for the most likely outcomes of the ones before (a tree: "if
+ * this proposal is rejected, the next one is ...; if accepted, ..."; likelihood of an outcome from the
+ * chain's own acceptance rates), up to `nodes` proposals per chain and call, and bh_chains_accept walks the
+ * tree along the outcomes that the likelihoods decide: a chain advances by 1 .. nodes iterations per call,
+ * chains of a pool no longer stand at the same iteration, and the samples are EXACTLY those of nodes = 1
+ * (same random draws in the same order; tests/test_chains.py).  The staging arrays of bh_chains_propose must
+ * then hold bh_chains_rows() = nchains * nodes rows.  Allowed whenever no results are outstanding. */
+#define BH_CHAIN_MAX_LOOKAHEAD 512
+int  bh_chains_set_lookahead(bh_chain_pool *pool, int nodes);
+int  bh_chains_lookahead(const bh_chain_pool *pool);
+long bh_chains_rows(const bh_chain_pool *pool);
+/* totals since creation, initial models not counted: propose/accept pairs, chain iterations they completed
+ * (all chains), models they handed out; any pointer may be NULL */
+int  bh_chains_advance(const bh_chain_pool *pool, long *calls, long *iterations, long *rows);
+int  bh_chains_iterations(const bh_chain_pool *pool, long *iter);   /* iter[nchains]: each chain's next iteration */
 /* per-chain bookkeeping; any pointer may be NULL.  naccepted = rows stored so far (the reference's
  * self.n), propdist[nchains][5], accepted/proposed[nchains][5] as in adjust_propdist */
 int  bh_chains_counters(const bh_chain_pool *pool, long *naccepted, double *propdist,

@@ -105,7 +105,7 @@ def oracle_evaluator(joint):
     return run
 
 
-def make_pool(oracle, data_dir, case, seeds, groups=None, evaluator=None):
+def make_pool(oracle, data_dir, case, seeds, groups=None, evaluator=None, lookahead=None):
     from bayhunter_amd.chains import ChainPool
     refs = case.get('refs', TWO)
     if evaluator is None:
@@ -116,4 +116,4 @@ def make_pool(oracle, data_dir, case, seeds, groups=None, evaluator=None):
         evaluator = evaluator(joint)
     ip = dict(case['initparams'], iter_burnin=case['burnin'], iter_main=case['main'])
     return ChainPool(joint, initparams=ip, modelpriors=case['priors'], seeds=seeds, evaluator=evaluator,
-                     groups=groups)
+                     groups=groups, lookahead=lookahead)

@@ -313,6 +313,72 @@ def test_threads_and_pool_interleaving_do_not_change_chains(lib):
             assert np.array_equal(getattr(other, k), getattr(ref, k)[:n], equal_nan=True), k
 
 
+def test_lookahead_does_not_change_chains(lib):
+    """bh_chains_set_lookahead: with 2 .. 64 proposals per chain and call -- the following iterations for the likeliest
+    outcomes -- every chain stores exactly the samples of the one-proposal-per-call chain, ends with the same counters,
+    proposal widths and random stream, and the pool needs fewer calls.  Long enough to cross the iterations at which the
+    proposal widths adapt (every 1000th; the look-ahead stops there) and the end of the early phase (1 %)."""
+    from bayhunter_amd import _lib
+    from chain_scenario import joint_target
+    from bayhunter_amd.chains import ChainPool
+    case = CASES['tutorial']
+
+    def toy(packed, nlay, noise):
+        vs, h = packed[:, 2, :], packed[:, 0, :]
+        d = vs[:, 0] - 3.1 + 0.01 * nlay + 0.002 * h.sum(axis=1)
+        return -40. * d * d - 3. * noise[:, 3], np.stack([np.abs(d), np.abs(d), 2 * np.abs(d)], axis=1)
+
+    def run(lookahead, groups=1, n=24):
+        ip = dict(case['initparams'], iter_burnin=1700, iter_main=700, acceptance=(40, 45))
+        pool = ChainPool(joint_target(DATA), initparams=ip, modelpriors=case['priors'], seeds=(np.arange(n) * 13) % 1000,
+                         evaluator=toy, groups=groups, lookahead=lookahead, nmodels=2401)
+        pool.run()
+        rng = []
+        for g in pool.groups:
+            for ci in range(g.n):
+                key, pos, hg, gs = np.zeros(624, dtype=np.uint32), C.c_int(), C.c_int(), C.c_double()
+                _lib.check(lib.bh_chains_get_rng(g.handle, ci, key.ctypes.data, C.byref(pos), C.byref(hg), C.byref(gs)))
+                rng.append((key.tobytes(), pos.value, hg.value, gs.value))
+        return pool, rng
+
+    ref, ref_rng = run(1)
+    calls, iters, rows = ref.advance()
+    assert calls == 2400 and iters == 24 * 2400 and rows == ref.evaluated - 24 and ref.lookahead == 1
+    assert len(set(ref.counters()[0])) > 5                      # (the chains differ)
+    for la, groups in ((2, 1), (5, 2), (16, 1), (64, 3)):
+        pool, rng = run(la, groups)
+        assert pool.lookahead == la and pool.iteration == 700
+        for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
+            assert np.array_equal(getattr(pool, k), getattr(ref, k), equal_nan=True), (la, k)
+        for a, b in zip(pool.counters(), ref.counters()):
+            assert np.array_equal(a, b), la
+        assert rng == ref_rng, la
+        c, i, r = pool.advance()
+        assert i == iters and c < calls * groups / min(la, 1.5) and r <= c * la * 24 / groups + 24
+    # the staging arrays hold nchains * lookahead rows; the setting is refused while results are due and out of range
+    g = pool.groups[0]
+    assert lib.bh_chains_rows(g.handle) == g.n * 64 == g.packed.shape[0] and lib.bh_chains_lookahead(g.handle) == 64
+    assert lib.bh_chains_set_lookahead(g.handle, 0) == _lib.BH_ERR_ARG and lib.bh_chains_set_lookahead(g.handle, 65) == _lib.BH_ERR_ARG
+    with pytest.raises(ValueError):
+        ChainPool(joint_target(DATA), initparams=case['initparams'], modelpriors=case['priors'], seeds=[1], evaluator=toy, lookahead=65)
+
+
+def test_lookahead_chain_is_the_golden_chain(oracle, golden_chains):
+    """The committed reference chains (real forward values from the oracle) with a look-ahead of 6 proposals."""
+    for name in sorted(CASES):
+        case = CASES[name]
+        seeds = [int(s) for s in golden_chains['%s/seeds' % name]]
+        pool = make_pool(oracle, DATA, case, seeds=seeds, groups=1, lookahead=6).run()
+        counts = pool.counters()[0]
+        for i, seed in enumerate(seeds):
+            got = pool.chain(i)
+            assert got['n'] == int(golden_chains['%s/%d/n' % (name, seed)]) == counts[i]
+            _same({k: golden_chains['%s/%d/%s' % (name, seed, k)] for k in
+                   ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter')}, got, (name, seed))
+        calls, iters, rows = pool.advance()
+        assert iters == len(seeds) * (case['burnin'] + case['main']) and calls < 0.6 * (case['burnin'] + case['main'])
+
+
 def test_move_and_acceptance_queries(lib):
     """bh_chains_moves / bh_chains_accepted: per model of the last batch, which move produced it and
     whether it became the chain's current model; consistent with the stored samples."""

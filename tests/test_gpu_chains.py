@@ -69,6 +69,28 @@ def test_gpu_pool_many_chains_lockstep_and_files(tmp_path):
         assert np.array_equal(small.chain(0)[k], pool.chain(0)[k], equal_nan=True)
 
 
+def test_gpu_pool_lookahead_same_chains_in_fewer_calls():
+    """The default pool on the GPU looks ahead (a call of a small pool is bound by its latency, not its size:
+    bh_chains_set_lookahead): bit for bit the chains of the one-proposal-per-call pool -- every kernel form gives a
+    model the same values wherever it stands in a batch -- in a fraction of the device calls."""
+    case = dict(CASES['tutorial'], burnin=1250, main=250)
+    case['initparams'] = dict(case['initparams'], acceptance=(40, 100))
+    seeds = list(range(40, 52))
+    one = make_pool(None, DATA, case, seeds=seeds, evaluator=gpu_evaluator, lookahead=1).run()
+    auto = make_pool(None, DATA, case, seeds=seeds, evaluator=gpu_evaluator).run()
+    assert one.lookahead == 1 and auto.lookahead == 64
+    for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
+        assert np.array_equal(getattr(one, k), getattr(auto, k), equal_nan=True), k
+    for a, b in zip(one.counters(), auto.counters()):
+        assert np.array_equal(a, b)
+    c1, i1, r1 = one.advance()
+    c2, i2, r2 = auto.advance()
+    assert c1 == 1500 and i1 == i2 == 12 * 1500 and c2 < c1 / 4 and r2 > r1
+    one.close()
+    auto.close()
+    assert auto.advance() == (c2, i2, r2)                           # (kept by a closed pool)
+
+
 def test_gpu_pool_result_files_match_the_reference_files(tmp_path):
     """SURVEY 8(f4) on the tier the driver runs: ChainPool.save() after a GPU-evaluated run against
     the ten files the reference's own chain writes (tests/golden/chain_files_golden.npz: weighting by

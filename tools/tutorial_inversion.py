@@ -3,7 +3,8 @@
 lock-step chain pool, and a summary of what the chains found next to the model the data were
 computed from (tutorial/create_testdata.py: h = 5, 23, 8 km, vs = 2.7, 3.6, 3.8, 4.4 km/s,
 vp/vs 1.73; noise added to the data).
-usage: python tools/tutorial_inversion.py [nchains] [iter_burnin] [iter_main]"""
+usage: python tools/tutorial_inversion.py [nchains] [iter_burnin] [iter_main] [lookahead]
+(tutorialhunt.py itself: 5 chains, 2048*32 + 2048*16 iterations; lookahead: proposals per chain and call, default the pool's)"""
 import json
 import os
 import sys
@@ -23,6 +24,7 @@ def main():
     nchains = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     burnin = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
     main_it = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+    lookahead = int(sys.argv[4]) if len(sys.argv) > 4 else None
     d = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
     sw, rf = np.loadtxt(os.path.join(d, 'st3_rdispph.dat')), np.loadtxt(os.path.join(d, 'st3_prf.dat'))
     joint = T.JointTarget([T.RayleighDispersionPhase(sw[:, 0], sw[:, 1]), T.PReceiverFunction(rf[:, 0], rf[:, 1])])
@@ -34,11 +36,14 @@ def main():
               acceptance=(40, 45), thickmin=0.1, lvz=None, hvz=None, rcond=1e-5, station='st3', maxmodels=50000)
     # the reference sizes its sample arrays by max(acceptance) = 45 % of the iterations; a chain that
     # runs hotter overflows them (IndexError there).  Short runs do: give every chain full storage.
+    from bayhunter_amd import _lib
+    import hashlib
     pool = ChainPool(joint, initparams=ip, modelpriors=priors, random_seed=1, nchains=nchains,
-                     nmodels=burnin + main_it + 1)
+                     nmodels=burnin + main_it + 1, lookahead=lookahead,
+                     groups=int(os.environ['BH_GROUPS']) if 'BH_GROUPS' in os.environ else None)
     t0 = time.perf_counter()
     try:
-        pool.run(progress=(500, lambda p: print('iteration', p.iteration, 'evaluated', p.evaluated,
+        pool.run(progress=(2000, lambda p: print('iteration', p.iteration, 'evaluated', p.evaluated,
                                                  '%.1f s' % (time.perf_counter() - t0), flush=True)))
     except Exception as e:
         print('stopped:', e)
@@ -64,7 +69,11 @@ def main():
                                vpvs=round(float(pool.vpvs[best, last[best]]), 3),
                                noise=[float(x) for x in pool.noise[best, last[best]]]),
                true_model=dict(h=[5, 23, 8, 0], vs=[2.7, 3.6, 3.8, 4.4], vpvs=1.73),
-               host_seconds={k: round(v, 2) for k, v in pool.seconds.items()})
+               host_seconds={k: round(v, 2) for k, v in pool.seconds.items()},
+               lookahead=pool.lookahead, device_calls=pool.advance()[0],
+               chains_sha256=hashlib.sha256(b''.join(np.ascontiguousarray(a).tobytes() for a in
+                                                     (pool.models, pool.likes, pool.iter, pool.noise, pool.vpvs))).hexdigest()[:16],
+               library=_lib.source_hash())
     print(json.dumps(out))
 
 
