@@ -37,8 +37,8 @@ DEFAULT_INITPARAMS = dict(nchains=3, iter_burnin=2048 * 2, iter_main=2048, propd
                           station='test', savepath='results/', maxmodels=50000)
 
 
-LOOKAHEAD_MAX = 512       # BH_CHAIN_MAX_LOOKAHEAD
-LOOKAHEAD_ROWS = 2048     # models per device call the default look-ahead aims at (profiles/r04_lookahead_sweep.txt)
+LOOKAHEAD_MAX = 64        # BH_CHAIN_MAX_LOOKAHEAD
+LOOKAHEAD_SCALE = 128.    # default look-ahead = LOOKAHEAD_SCALE / sqrt(chains per group) (profiles/r04_lookahead_sweep.txt)
 
 
 def _is_number(x):
@@ -194,9 +194,10 @@ class ChainPool(object):
     lookahead    proposals per chain and device call (1 .. 64; bh_chains_set_lookahead): with more than one, a
                  chain also hands in the proposals of its following iterations for the likeliest outcomes of
                  the ones before and advances by as many iterations as the likelihoods confirm -- the same
-                 samples in fewer, larger device calls.  Default: enough to give a call of a group about
-                 LOOKAHEAD_ROWS models when the evaluator is the GPU's (small pools are bound by the latency
-                 of a call, not by its size), 1 for any other evaluator.
+                 samples in fewer, larger device calls.  Default: LOOKAHEAD_SCALE / sqrt(chains per group)
+                 when the evaluator is the GPU's (small pools are bound by the latency of a call more than by
+                 its size: 57 proposals per chain for 5 chains, 16 for 64, 4 for 1 024, 1 from 16 384 per
+                 group), 1 for any other evaluator.
     shard        (rank, world): this process runs only its contiguous block of the nchains chains
                  (distributed.shard_range), one process per GPU.  Seeds are drawn for ALL chains
                  first, so chain c is the same chain whatever the number of ranks; chains never
@@ -272,7 +273,7 @@ class ChainPool(object):
         bounds = [(g * self.nchains) // groups for g in range(groups + 1)]
         if lookahead is None:
             per_group = max(1, self.nchains // groups)
-            lookahead = max(2 if per_group <= LOOKAHEAD_ROWS else 1, min(LOOKAHEAD_MAX, LOOKAHEAD_ROWS // per_group)) \
+            lookahead = max(1, min(LOOKAHEAD_MAX, int(LOOKAHEAD_SCALE / np.sqrt(per_group)))) \
                 if isinstance(evaluator, GpuEvaluator) else 1
         self.lookahead = int(lookahead)
         if not 1 <= self.lookahead <= LOOKAHEAD_MAX:

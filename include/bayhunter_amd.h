@@ -352,7 +352,7 @@ long bh_chains_iteration(const bh_chain_pool *pool);       /* the slowest chain'
  * chains of a pool no longer stand at the same iteration, and the samples are EXACTLY those of nodes = 1
  * (same random draws in the same order; tests/test_chains.py).  The staging arrays of bh_chains_propose must
  * then hold bh_chains_rows() = nchains * nodes rows.  Allowed whenever no results are outstanding. */
-#define BH_CHAIN_MAX_LOOKAHEAD 512
+#define BH_CHAIN_MAX_LOOKAHEAD 64
 int  bh_chains_set_lookahead(bh_chain_pool *pool, int nodes);
 int  bh_chains_lookahead(const bh_chain_pool *pool);
 long bh_chains_rows(const bh_chain_pool *pool);

@@ -39,8 +39,7 @@ def main():
     from bayhunter_amd import _lib
     import hashlib
     pool = ChainPool(joint, initparams=ip, modelpriors=priors, random_seed=1, nchains=nchains,
-                     nmodels=burnin + main_it + 1, lookahead=lookahead,
-                     groups=int(os.environ['BH_GROUPS']) if 'BH_GROUPS' in os.environ else None)
+                     nmodels=burnin + main_it + 1, lookahead=lookahead)
     t0 = time.perf_counter()
     try:
         pool.run(progress=(2000, lambda p: print('iteration', p.iteration, 'evaluated', p.evaluated,
