@@ -24,8 +24,10 @@ struct Pool {
     std::vector<int> nlay, chain;
     std::vector<unsigned> seeds;
     bh_chain_pool *p = nullptr;
-    Pool(int nchains, long iters) : n(nchains), L(12), nm(iters + 2)
+    Pool(int nchains, long iters, int lookahead = 1) : n(nchains), L(12), nm(iters + 2)
     {
+        const int n1 = nchains;                       // chains; n: rows of the staging arrays
+        n = nchains * lookahead;
         bh_chain_config c;
         std::memset(&c, 0, sizeof(c));
         c.ntargets = 2; c.layers_min = 1; c.layers_max = 10;
@@ -41,14 +43,15 @@ struct Pool {
         c.noise_lo[2] = 0.3; c.noise_hi[2] = 0.9;
         c.noise_lo[3] = 1e-5; c.noise_hi[3] = 0.05;
         const int W = 2 * (c.layers_max + 1), T = c.ntargets;
-        models.assign((size_t)n * nm * W, NAN); misfits.assign((size_t)n * nm * (T + 1), NAN);
-        likes.assign((size_t)n * nm, NAN); noise.assign((size_t)n * nm * 2 * T, NAN); vpvs.assign((size_t)n * nm, NAN);
-        iter.assign((size_t)n * nm, NAN);
+        models.assign((size_t)n1 * nm * W, NAN); misfits.assign((size_t)n1 * nm * (T + 1), NAN);
+        likes.assign((size_t)n1 * nm, NAN); noise.assign((size_t)n1 * nm * 2 * T, NAN); vpvs.assign((size_t)n1 * nm, NAN);
+        iter.assign((size_t)n1 * nm, NAN);
         packed.assign((size_t)n * 4 * L, 0); pnoise.assign((size_t)n * 2 * T, 0); logL.assign(n, 0); mis.assign((size_t)n * (T + 1), 0);
-        nlay.assign(n, 0); chain.assign(n, 0); seeds.resize(n);
-        for (int i = 0; i < n; i++) seeds[i] = (unsigned)(i * 7 + 1) % 1000;
+        nlay.assign(n, 0); chain.assign(n, 0); seeds.resize(n1);
+        for (int i = 0; i < n1; i++) seeds[i] = (unsigned)(i * 7 + 1) % 1000;
         bh_chain_storage st = {nm, models.data(), misfits.data(), likes.data(), noise.data(), vpvs.data(), iter.data()};
-        if (bh_chains_create(&c, n, seeds.data(), &st, &p) != BH_OK) { std::printf("create: %s\n", bh_last_error()); std::exit(2); }
+        if (bh_chains_create(&c, n1, seeds.data(), &st, &p) != BH_OK) { std::printf("create: %s\n", bh_last_error()); std::exit(2); }
+        if (bh_chains_set_lookahead(p, lookahead) != BH_OK || bh_chains_rows(p) != n) { std::printf("lookahead: %s\n", bh_last_error()); std::exit(2); }
     }
     ~Pool() { bh_chains_destroy(p); }
     bool step()
@@ -82,7 +85,10 @@ int main(int argc, char **argv)
     // "ascending": the smallest pool steps first, so the helper-thread set GROWS after the first
     // job has been published (a worker created then must not react to the earlier generations)
     const bool ascending = argc > 2 && std::string(argv[2]) == "ascending";
-    Pool a(3000, 60), b(700, 40), c(130, 90);        // 8-, 5- and 1-part jobs interleave
+    // "lookahead" (third argument): the pools draw 2, 5 and 16 proposals per chain and call (bh_chains_set_lookahead) --
+    // the checksums are those of one proposal per call
+    const bool ahead = argc > 3 && std::string(argv[3]) == "lookahead";
+    Pool a(3000, 60, ahead ? 2 : 1), b(700, 40, ahead ? 5 : 1), c(130, 90, ahead ? 16 : 1);        // 8-, 5- and 1-part jobs interleave
     for (Pool *q : {&a, &b, &c}) bh_chains_set_threads(q->p, threads);
     std::vector<Pool *> order = {&a, &b, &c};
     if (ascending) order = {&c, &b, &a};

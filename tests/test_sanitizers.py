@@ -13,7 +13,7 @@ SRC = [os.path.join(ROOT, 'tests', 'sanitize', 'chains_driver.cpp'),
        os.path.join(ROOT, 'bayhunter_amd', 'csrc', 'chains.cpp')]
 
 
-def _run(tmp_path, flags, threads, env=None, order='descending'):
+def _run(tmp_path, flags, threads, env=None, order='descending', lookahead=False):
     exe = str(tmp_path / ('driver_' + '_'.join(f.strip('-=').replace(',', '_') for f in flags)))
     c = subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-pthread', '-ffp-contract=off'] + flags + SRC + ['-o', exe],
                        capture_output=True, text=True)
@@ -22,7 +22,8 @@ def _run(tmp_path, flags, threads, env=None, order='descending'):
     assert c.returncode == 0, c.stderr[-4000:]
     e = dict(os.environ, BH_CHAIN_SPIN_US='200')
     e.update(env or {})
-    r = subprocess.run([exe, str(threads), order], capture_output=True, text=True, timeout=600, env=e)
+    r = subprocess.run([exe, str(threads), order] + (['lookahead'] if lookahead else []), capture_output=True, text=True,
+                       timeout=600, env=e)
     if flags and ('unexpected memory mapping' in r.stderr or 'Shadow memory range interleaves' in r.stderr
                   or 'ReserveShadowMemoryRange failed' in r.stderr):
         pytest.skip('the sanitizer runtime cannot start in this environment: ' + r.stderr[-300:])
@@ -37,6 +38,10 @@ def test_chain_pool_host_code_under_asan_ubsan_and_tsan(tmp_path):
                 env={'ASAN_OPTIONS': 'detect_leaks=1', 'UBSAN_OPTIONS': 'print_stacktrace=1'})
     tsan = _run(tmp_path, ['-fsanitize=thread'], 8, env={'TSAN_OPTIONS': 'halt_on_error=1'})
     assert plain1 == asan == tsan
+    # the look-ahead trees (2, 5 and 16 proposals per chain and call): same samples, clean under both
+    assert _run(tmp_path, ['-fsanitize=address,undefined', '-fno-omit-frame-pointer'], 8, lookahead=True,
+                env={'ASAN_OPTIONS': 'detect_leaks=1', 'UBSAN_OPTIONS': 'print_stacktrace=1'}) == plain1
+    assert _run(tmp_path, ['-fsanitize=thread'], 8, env={'TSAN_OPTIONS': 'halt_on_error=1'}, lookahead=True) == plain1
     # smallest pool first: helper threads are created while earlier jobs have already been published
     # (the order smoke() -> a larger ChainPool, or tools/chain_bench.py with growing pools, produces)
     for _ in range(3):
