@@ -402,18 +402,7 @@ __device__ __forceinline__ void swd_team_body(const SwdArgs &A)
 
 // The narrower forms carry per-team liveness through the divergent driver call: ~199 registers, no
 // scratch, pinned to 2 waves per SIMD (with machine LICM on they wanted ~310 and spilled 48 bytes).
-__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team32_kernel(SwdArgs A)
-{
-    swd_team_body<32>(A);
-}
-__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team16_kernel(SwdArgs A)
-{
-    swd_team_body<16>(A);
-}
-__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team8_kernel(SwdArgs A)
-{
-    swd_team_body<8>(A);
-}
+// (the kernels swd_team32 / 16 / 8 are defined behind swd_tpl_body, further down)
 
 // ---------------------------------------------------------------------------------- SWD, wide teams
 // 64*W lanes (W waves, one workgroup) per search: swd_team.h, "Wide teams".  Per round
@@ -513,6 +502,62 @@ struct TeamwVals {
         int n;
         if (stride == 2) {
             const unsigned long long stop = ~m & 0x5555555555555555ull;     // scan slots are the even ones
+            n = stop ? (__ffsll((long long)stop) - 1) >> 1 : 32;
+        } else {
+            const unsigned long long stop = ~m;
+            n = stop ? __ffsll((long long)stop) - 1 : 64;
+        }
+        return n < count ? n : count;
+    }
+};
+
+// The same interface for a team of K < 64 lanes that shares its wave with other teams (swd_tpl_body): the teams of
+// a wave are at different places of the consuming loop, so nothing here may assume that the whole wave executes it
+// -- values and node outcomes are exchanged through the team's LDS block, and a ballot is cut down to the team's
+// lanes (all of which execute it together: they carry identical copies of the search state).
+template <int K>
+struct SubVals {
+    double mc, mom, dl;                   // slot tl of the round and its value
+    int nt, tl, base;                     // base: the team's first lane in the wave
+    const double *tc, *dls, *ndc;         // team LDS: trial velocities, values, node brackets [5][K]
+    const int *nout;                      // node outcomes [K]
+    unsigned long long left, right;       // nodes whose decision is SWD_GO_LEFT / SWD_GO_RIGHT (bit j = node j)
+    static constexpr unsigned long long MASK = (1ull << K) - 1;
+    __device__ __forceinline__ void probe(int) const {}
+    __device__ __forceinline__ void count(int, int) const {}
+    __device__ __forceinline__ unsigned long long mine(bool p) const { return (__ballot(p) >> base) & MASK; }
+    __device__ __forceinline__ int find(double om, double c) const
+    {
+        const unsigned long long m = mine(mc == c && mom == om && tl < nt);
+        return m ? __ffsll((long long)m) - 1 : -1;
+    }
+    __device__ __forceinline__ double del(int j) const { return dls[j]; }
+    __device__ __forceinline__ double c(int j) const { return tc[j]; }
+    __device__ __forceinline__ int go(const SwdState &, int j) const
+    {
+        return ((right >> j) & 1) ? SWD_GO_RIGHT : ((left >> j) & 1) ? SWD_GO_LEFT : SWD_GO_STOP;
+    }
+    __device__ __forceinline__ int chain_run(const SwdState &, int first, int dir, int max) const
+    {
+        const unsigned long long m = (dir == SWD_GO_RIGHT ? right : left) >> first;
+        const unsigned long long stop = ~m & 0x5555555555555555ull;
+        const int n = stop ? (__ffsll((long long)stop) - 1) >> 1 : 32;
+        return n < max ? n : max;
+    }
+    __device__ __forceinline__ TeamwNode node(const SwdState &, int j) const
+    {
+        TeamwNode a;
+        a.go = SWD_GO_STOP;
+        a.out = nout[j];
+        a.c1 = ndc[j]; a.d1 = ndc[K + j]; a.c2 = ndc[2 * K + j]; a.d2 = ndc[3 * K + j]; a.c3n = ndc[4 * K + j];
+        return a;
+    }
+    __device__ __forceinline__ int run(int first, int stride, int count, bool neg) const
+    {
+        const unsigned long long m = mine((mc == mc) && ((__double2hiint(dl) < 0) == neg) && tl < nt) >> first;
+        int n;
+        if (stride == 2) {
+            const unsigned long long stop = ~m & 0x5555555555555555ull;
             n = stop ? (__ffsll((long long)stop) - 1) >> 1 : 32;
         } else {
             const unsigned long long stop = ~m;
@@ -795,6 +840,94 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
     (void)rounds;
 }
 
+// ------------------------------------------------------------------------- SWD, narrow teams (8 / 16 / 32 lanes)
+// K lanes per search, 64 / K searches per wave, ONE TRIAL PER LANE: the plan, the matching and the tree walk are the
+// wide teams' (swd_teamw_round / swd_teamw_consume: scan, cell midpoints, bisection tree, the search that follows),
+// with K slots per round, but a lane evaluates its trial's period equation from the half-space to the surface by
+// itself -- swd_dltar4 / swd_dltar1 as in swd_kernel, no matrices in LDS, no second phase.  Between the lane kernel
+// (one lane, ~33 evaluations per period one behind the other) and a 64-lane team (one evaluation per round spread
+// over a trial's layers, ~4 rounds per period, a wave per search): K lanes take a search through in ~4-7 rounds per
+// period of one full evaluation each.  For the batches in between -- a few thousand to a few ten thousand searches,
+// which fill the chip as 64 / K searches per wave but not as one search per lane.
+// (Until round 4 the narrow forms spread the LAYERS of one or two trials over the team's lanes, like the wide teams,
+// and speculated on the scan only: 4.5 searches/us on five layers where the lane kernel does 16.8.  swd_team_body
+// below, -DBH_NARROW_LAYERS.)
+// Every lane of a team runs driver, plan and consuming loop on its own copy of the team's state; the teams of a wave
+// diverge there, and meet again for the evaluation.
+BH_HD int swd_tpl_team_doubles(int Lmax, int K)
+{
+    // tc, dls [K]; node brackets [5][K]; Neville table 24; node outcomes K ints; model 4 Lmax floats
+    return 7 * K + 24 + (K + 1) / 2 + (4 * Lmax + 1) / 2 + 1;
+}
+
+template <int K>
+__device__ __forceinline__ void swd_tpl_body(const SwdArgs &A)
+{
+    extern __shared__ double tlds[];
+    static_assert(K == 8 || K == 16 || K == 32, "8, 16 or 32 lanes per search");
+    const int sub = threadIdx.x / K, tl = threadIdx.x % K, base = sub * K;
+    const int t = blockIdx.y;
+    if (!((A.tmask >> t) & 1u)) return;              // not a target of this launch (kernels.h)
+    const SwdTargetDev tg = A.tg[t];
+    double *perl = tlds;                             // the target's periods, for all teams of the wave
+    double *mem = tlds + BH_NP + (long)sub * swd_tpl_team_doubles(A.Lmax, K);
+    double *tc = mem, *dls = tc + K, *ndc = dls + K, *nevt = ndc + 5 * K;
+    int *nout = (int *)(nevt + 24);
+    TeamLay lay{(float *)(nevt + 24 + (K + 1) / 2), A.Lmax};
+    for (int k = threadIdx.x; k < tg.nper; k += SWD_T) perl[k] = A.periods[tg.per_off + k];
+    __syncthreads();
+    TeamSrc src{A, tg, t, tl, K, 0, (long)blockIdx.x, A.counters + t, nullptr};
+    SwdState S;
+    swd_state_init(S);
+    NevMem nv{nevt, nevt + 12};
+    TeamwNext nxt{-1, -1, 0.0, 0, 0, 0.0, 0.0, 0.0};
+    TeamwRound R;
+    R.nt = 1; R.nhalf = 0; R.ngrp = 0;
+    bool live = true;
+    for (;;) {
+        if (live) {
+            if (S.ev != SWD_EV_NONE) swd_driver(S, lay, src, tg, perl, A.B, true);
+            live = S.st != SWD_ST_DONE;
+        }
+        if (!__any(live)) break;
+        double mc = __longlong_as_double(0x7ff8000000000000ll), mom = 0.0, dl = 0.0;
+        int nt = 0;
+        if (live) {
+            R = swd_teamw_round(S, tg, perl, K, nxt);
+            nt = R.nt;
+            if (tl < nt) swd_teamw_trial(R, S, tl, &mc, &mom);
+        }
+        if (live && tl < nt && mc == mc) {                               // (NaN: a scan slot out of bounds)
+            const double wvno = mom / mc;
+            dl = (tg.iwave == 1) ? swd_dltar1(lay, S.mmax, S.llw, wvno, mom) : swd_dltar4(lay, S.mmax, S.llw, wvno, mom);
+        }
+        tc[tl] = mc;
+        dls[tl] = dl;
+        __syncthreads();
+        unsigned long long goL = 0, goR = 0;
+        {
+            // refinement round: lane j works out node j of the bisection tree (what the search does when it arrives
+            // there), the consuming loop then follows the decisions
+            const bool innode = live && R.nhalf > 0 && tl <= R.nhalf;
+            TeamwNode nd;
+            nd.go = SWD_GO_STOP; nd.out = SWD_OUT_CONTROL; nd.c1 = nd.d1 = nd.c2 = nd.d2 = nd.c3n = 0.0;
+            if (innode) {
+                nd = swd_teamw_node(S, R, LdsSlots{dls, tc}, tl);
+                nout[tl] = nd.out;
+                ndc[tl] = nd.c1; ndc[K + tl] = nd.d1; ndc[2 * K + tl] = nd.c2; ndc[3 * K + tl] = nd.d2; ndc[4 * K + tl] = nd.c3n;
+            }
+            goL = (__ballot(innode && nd.go == SWD_GO_LEFT) >> base) & SubVals<K>::MASK;
+            goR = (__ballot(innode && nd.go == SWD_GO_RIGHT) >> base) & SubVals<K>::MASK;
+        }
+        __syncthreads();
+        if (live) {
+            SubVals<K> v{mc, mom, dl, nt, tl, base, tc, dls, ndc, nout, goL, goR};
+            (void)swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
+        }
+        __syncthreads();
+    }
+}
+
 // Three waves per SIMD: <= 168 VGPRs (the body needs ~140; without the bound the register allocator spreads out
 // to 189 and, with the 12.9 KB of LDS a 64-lane team takes, the registers would be what limits a CU to eight teams).
 #define BH_TEAMW_ATTR __attribute__((amdgpu_waves_per_eu(3)))
@@ -802,6 +935,15 @@ __global__ __launch_bounds__(SWD_T) BH_TEAMW_ATTR void swd_team_kernel(SwdArgs A
 __global__ __launch_bounds__(2 * SWD_T) BH_TEAMW_ATTR void swd_team128_kernel(SwdArgs A) { swd_teamw_body<2>(A); }
 __global__ __launch_bounds__(4 * SWD_T) BH_TEAMW_ATTR void swd_team256_kernel(SwdArgs A) { swd_teamw_body<4>(A); }
 __global__ __launch_bounds__(8 * SWD_T) BH_TEAMW_ATTR void swd_team512_kernel(SwdArgs A) { swd_teamw_body<8>(A); }
+
+#if defined(BH_NARROW_LAYERS)
+#define BH_NARROW_BODY swd_team_body
+#else
+#define BH_NARROW_BODY swd_tpl_body
+#endif
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team32_kernel(SwdArgs A) { BH_NARROW_BODY<32>(A); }
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team16_kernel(SwdArgs A) { BH_NARROW_BODY<16>(A); }
+__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team8_kernel(SwdArgs A) { BH_NARROW_BODY<8>(A); }
 
 // -------------------------------------------------------------------------------------------- RF
 // bit reversal (+ 1/sqrt(n)) and radix-2 butterflies of Mb buffers in LDS; all threads of the group
@@ -961,8 +1103,12 @@ size_t swd_team_lds_bytes(int Lmax, int team)
         return ((size_t)swd_mat_off(nm) + 3 * SWD_TEAMW_NT + BH_NP + 24 * (team / SWD_T) + BH_NP / 2 + (4 * Lmax + 1) / 2) * sizeof(double);
     }
     const int nsub = SWD_T / team;
+#if defined(BH_NARROW_LAYERS)
     const int nm = Lmax > team ? Lmax : team;
     return (size_t)nsub * (nm * SWD_NCA + 2 * SWD_TEAM_NT + (4 * Lmax + 1) / 2) * sizeof(double);
+#else
+    return ((size_t)BH_NP + (size_t)nsub * swd_tpl_team_doubles(Lmax, team)) * sizeof(double);
+#endif
 }
 
 static int team_index(int team)

@@ -25,6 +25,13 @@ SHAPES = [  # name, layers, periods, lanes, igr
     ('cfg4 15 layers x 256 lanes', 15, 21, 256, 0),
     ('cfg4 15 layers x 512 lanes', 15, 21, 512, 0),
     ('cfg3 rdispgr 10 layers x 128 lanes', 10, 40, 128, 1),
+    # narrow teams, one trial per lane (swd_tpl_body): slots per round = lanes
+    ('10 layers x 8 lanes', 10, 21, 8, 0),
+    ('10 layers x 16 lanes', 10, 21, 16, 0),
+    ('10 layers x 32 lanes', 10, 21, 32, 0),
+    ('cfg5 ragged x 16 lanes', (2, 31), 21, 16, 0),
+    ('cfg3 rdispgr 10 layers x 8 lanes', 10, 40, 8, 1),
+    ('cfg3 ldispph 10 layers x 8 lanes', 10, 40, 8, 0, 1),
 ]
 ST = ['A (entry)', 'B (scan)', 'TOP', 'MID']
 
@@ -40,7 +47,9 @@ def main():
     raw = C.CDLL(so)
     hs = conftest._wrap_hostsim(raw)
     from bayhunter_amd.synthetic import draw_models
-    for name, L, P, lanes, igr in SHAPES:
+    for shape in SHAPES:
+        name, L, P, lanes, igr = shape[:5]
+        iwave = 2 if len(shape) < 6 else shape[5]
         H, VP, VS, RHO, nl = draw_models(n, L, seed=100 + (L if isinstance(L, int) else 99), sorted_vs=True)
         per = np.linspace(1, 41, P)
         hist = np.zeros(4 * 3 * 16, dtype=np.int64)
@@ -48,7 +57,7 @@ def main():
         calls = spec = rounds = 0
         for b in range(n):
             k = nl[b]
-            _, e, nc, ns, nr = hs.swd_team(H[b, :k], VP[b, :k], VS[b, :k], RHO[b, :k], per, 2, igr, 1, 0, lanes, wide=True)
+            _, e, nc, ns, nr = hs.swd_team(H[b, :k], VP[b, :k], VS[b, :k], RHO[b, :k], per, iwave, igr, 1, 0, lanes, wide=True)
             assert e >= 0, e
             calls += nc; spec += ns; rounds += nr
         raw.hs_teamw_set_histogram(None)
