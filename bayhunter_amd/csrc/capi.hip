@@ -434,13 +434,26 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
         const double f = (std::log(s) - std::log(S[i])) / (std::log(S[i + 1]) - std::log(S[i]));
         return t[i] + f * (t[i + 1] - t[i]);
     };
+    // Targets that are not the table's (one Rayleigh phase velocity at 21 periods): the call's work is that of
+    // B x sum of the target weights such searches, and it cannot be shorter than the form's latency for the heaviest
+    // target (x 0.7: a search of weight w is w times the evaluations, not w times the rounds).  Four targets x 40
+    // periods on ten layers, 2 048 / 4 096 / 8 192 / 16 384 models: this picks 16- / 16- / 8-lane teams / the lane
+    // kernel -- measured best of the uniform plans: 16 / 8 (16: +17 %) / 8 / lane (profiles/r04_mixed_tpl.txt).
+    double wsum = 0.0, wmax = 0.0;
+    for (int t = 0; t < ntargets; t++) {
+        const double w = target_weight(targets[t]);
+        wsum += w;
+        wmax = std::fmax(wmax, w);
+    }
+    const double eff = (double)B * wsum * scale;
+    const double heavy = std::fmax(1.0, 0.7 * wmax);
     int uniform = 0;
     double best = 1e300;
     for (int k = 0; k < 8; k++) {
         if (!allowed(k)) continue;
-        double cost = form_ms(k, (double)searches * scale);
+        double cost = std::fmax(heavy * (double)bh::kFormMs[regime][k][0], form_ms(k, eff));
         if (regime_thr != regime || load > 1)         // ragged batch / shared chip: latency of the deepest | throughput
-            cost = std::fmax((double)bh::kFormMs[regime][k][0], form_ms_in(regime_thr, k, (double)searches * scale * load));
+            cost = std::fmax(heavy * (double)bh::kFormMs[regime][k][0], form_ms_in(regime_thr, k, eff * load));
         if (cost < best) { best = cost; uniform = k; }
     }
     int form[bh::BH_NT];

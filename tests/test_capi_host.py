@@ -161,10 +161,11 @@ def test_bench_evaluation_counts_are_the_oracles():
     assert (counts, lmean) == bench.N_DLTAR['joint10']
 
 
-def test_form_plan_moves_the_heaviest_target_of_a_latency_bound_call():
-    """bh_swd_plan_forms (host only): one form per call where one form is right -- a handful of models (wide
-    teams), a saturated chip (lane kernel), a single target -- and the Rayleigh group velocities of BASELINE cfg3
-    on 128-lane teams (8-lane teams for shallow models) beside the lane kernel for the other three targets."""
+def test_form_plan_follows_the_measured_table():
+    """bh_swd_plan_forms (host only): one form per call by the measured table (swd_form_table.h) -- a handful of models
+    on wide teams, a few thousand on the narrow ones (one trial per lane, round 4), a saturated chip on the lane kernel
+    -- with the call's work counted in table searches (BASELINE cfg3: four targets x 40 periods are 7.9 of them per
+    model) and its heaviest target bounding the latency."""
     import ctypes as C
     from bayhunter_amd import _lib
     lib = _lib.load()
@@ -179,22 +180,23 @@ def test_form_plan_moves_the_heaviest_target_of_a_latency_bound_call():
         _lib.check(lib.bh_swd_plan_forms(B, L, len(specs), tg, 256, forms))
         return list(forms)
     cfg3 = [(2, 0, 40), (2, 1, 40), (1, 0, 40), (1, 1, 40)]
-    assert plan(8192, 10, cfg3) == [0, 128, 0, 0] and plan(8192, 5, cfg3) == [0, 8, 0, 0]
+    assert plan(8192, 10, cfg3) == [8] * 4 and plan(8192, 5, cfg3) == [8] * 4
+    assert plan(2048, 10, cfg3) == [16] * 4 and plan(16384, 10, cfg3) == [0] * 4
     assert plan(64, 10, cfg3) == [512] * 4 and plan(524288, 10, cfg3) == [0] * 4
-    assert plan(12288, 10, [(2, 0, 21)]) == [64] and plan(524288, 10, [(2, 0, 21)]) == [0]
+    assert plan(12288, 10, [(2, 0, 21)]) == [16] and plan(524288, 10, [(2, 0, 21)]) == [0]
     # a sampler's ragged batch (proposals of a tutorial pool: 2-14 layers, 4.8 on average): priced by its mean depth and
     # by the number of batches in flight once the caller says so (bh_swd_hint), by its deepest model otherwise
     one = [(2, 0, 21)]
-    assert plan(4096, 14, one) == [128]
+    assert plan(4096, 14, one) == [16]
     _lib.check(lib.bh_swd_hint(4.8, 2))
     assert plan(4096, 14, one) == [64]
-    assert plan(4096, 14, one) == [128]                      # a hint is about one call
+    assert plan(4096, 14, one) == [16]                       # a hint is about one call
     _lib.check(lib.bh_swd_hint(4.8, 1))
     assert plan(8192, 14, one) == [64]
     _lib.check(lib.bh_swd_hint(4.8, 1))
     assert plan(2048, 14, one) == [128]                      # the deepest model's latency still bounds a small batch
     _lib.check(lib.bh_swd_hint(16.75, 1))
-    assert plan(8192, 31, one) == [128]                      # BASELINE cfg5: unchanged
+    assert plan(8192, 31, one) == [16]                       # BASELINE cfg5: 16 lanes per search, one trial each
     assert lib.bh_swd_hint(-1.0, 1) != 0 and lib.bh_swd_hint(3.0, 0) != 0
     for B in (1, 64, 1024, 8192, 65536):
         for L in (3, 10, 30):
