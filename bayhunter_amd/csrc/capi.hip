@@ -646,6 +646,11 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
         A.nsel = l.n;
         A.tmask = 0;
         for (int k = 0; k < l.n; k++) A.tmask |= 1u << l.sel[k];
+        for (int k = 0; k < l.n; k++) {                       // heaviest first (insertion sort, at most BH_NT entries)
+            int i = k;
+            while (i > 0 && target_weight(targets[A.tord[i - 1]]) < target_weight(targets[l.sel[k]])) { A.tord[i] = A.tord[i - 1]; i--; }
+            A.tord[i] = l.sel[k];
+        }
         if (l.width > 0) {
             int w = l.width;
             while (w > 64 && bh::swd_team_lds_bytes(Lmax, w) > 160 * 1024) w /= 2;

@@ -35,6 +35,7 @@ struct SwdArgs {
     // them the co-residency with rf_kernel: 2 x 192 + 128 is all a SIMD has.)
     unsigned int tmask;
     int nsel;
+    unsigned char tord[BH_NT];   // the launch's targets, heaviest first (narrow teams: the order in which every wave drains them)
 };
 
 struct RfArgs {

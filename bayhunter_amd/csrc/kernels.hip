@@ -866,65 +866,73 @@ __device__ __forceinline__ void swd_tpl_body(const SwdArgs &A)
     extern __shared__ double tlds[];
     static_assert(K == 8 || K == 16 || K == 32, "8, 16 or 32 lanes per search");
     const int sub = threadIdx.x / K, tl = threadIdx.x % K, base = sub * K;
-    const int t = blockIdx.y;
-    if (!((A.tmask >> t) & 1u)) return;              // not a target of this launch (kernels.h)
-    const SwdTargetDev tg = A.tg[t];
     double *perl = tlds;                             // the target's periods, for all teams of the wave
     double *mem = tlds + BH_NP + (long)sub * swd_tpl_team_doubles(A.Lmax, K);
     double *tc = mem, *dls = tc + K, *ndc = dls + K, *nevt = ndc + 5 * K;
     int *nout = (int *)(nevt + 24);
     TeamLay lay{(float *)(nevt + 24 + (K + 1) / 2), A.Lmax};
-    for (int k = threadIdx.x; k < tg.nper; k += SWD_T) perl[k] = A.periods[tg.per_off + k];
-    __syncthreads();
-    TeamSrc src{A, tg, t, tl, K, 0, (long)blockIdx.x, A.counters + t, nullptr};
-    SwdState S;
-    swd_state_init(S);
-    NevMem nv{nevt, nevt + 12};
-    TeamwNext nxt{-1, -1, 0.0, 0, 0, 0.0, 0.0, 0.0};
-    TeamwRound R;
-    R.nt = 1; R.nhalf = 0; R.ngrp = 0;
-    bool live = true;
-    for (;;) {
-        if (live) {
-            if (S.ev != SWD_EV_NONE) swd_driver(S, lay, src, tg, perl, A.B, true);
-            live = S.st != SWD_ST_DONE;
-        }
-        if (!__any(live)) break;
-        double mc = __longlong_as_double(0x7ff8000000000000ll), mom = 0.0, dl = 0.0;
-        int nt = 0;
-        if (live) {
-            R = swd_teamw_round(S, tg, perl, K, nxt);
-            nt = R.nt;
-            if (tl < nt) swd_teamw_trial(R, S, tl, &mc, &mom);
-        }
-        if (live && tl < nt && mc == mc) {                               // (NaN: a scan slot out of bounds)
-            const double wvno = mom / mc;
-            dl = (tg.iwave == 1) ? swd_dltar1(lay, S.mmax, S.llw, wvno, mom) : swd_dltar4(lay, S.mmax, S.llw, wvno, mom);
-        }
-        tc[tl] = mc;
-        dls[tl] = dl;
+    // Every wave of a launch drains the targets' queues one after the other, heaviest target first (A.tord; whatever
+    // blockIdx.y says): the targets of a call differ in weight by a factor of three (BASELINE cfg3: Rayleigh group
+    // velocities 3.2, Love phase velocities 1.1 table searches per model, capi.hip: target_weight), and with a fixed
+    // share of the waves each the call took as long as its heaviest target on a quarter of the chip -- and how long
+    // that was depended on which waves the dispatcher had happened to pair on a SIMD (15.1 or 17.2 ms for the same
+    // launch, profiles/r04_order_effect.txt).  Longest searches first is the list-scheduling order.
+    for (int it = 0; it < A.nsel; it++) {
+        const int t = A.tord[it];
+        const SwdTargetDev tg = A.tg[t];
         __syncthreads();
-        unsigned long long goL = 0, goR = 0;
-        {
-            // refinement round: lane j works out node j of the bisection tree (what the search does when it arrives
-            // there), the consuming loop then follows the decisions
-            const bool innode = live && R.nhalf > 0 && tl <= R.nhalf;
-            TeamwNode nd;
-            nd.go = SWD_GO_STOP; nd.out = SWD_OUT_CONTROL; nd.c1 = nd.d1 = nd.c2 = nd.d2 = nd.c3n = 0.0;
-            if (innode) {
-                nd = swd_teamw_node(S, R, LdsSlots{dls, tc}, tl);
-                nout[tl] = nd.out;
-                ndc[tl] = nd.c1; ndc[K + tl] = nd.d1; ndc[2 * K + tl] = nd.c2; ndc[3 * K + tl] = nd.d2; ndc[4 * K + tl] = nd.c3n;
+        for (int k = threadIdx.x; k < tg.nper; k += SWD_T) perl[k] = A.periods[tg.per_off + k];
+        __syncthreads();
+        TeamSrc src{A, tg, t, tl, K, 0, (long)blockIdx.x, A.counters + t, nullptr};
+        SwdState S;
+        swd_state_init(S);
+        NevMem nv{nevt, nevt + 12};
+        TeamwNext nxt{-1, -1, 0.0, 0, 0, 0.0, 0.0, 0.0};
+        TeamwRound R;
+        R.nt = 1; R.nhalf = 0; R.ngrp = 0;
+        bool live = true;
+        for (;;) {
+            if (live) {
+                if (S.ev != SWD_EV_NONE) swd_driver(S, lay, src, tg, perl, A.B, true);
+                live = S.st != SWD_ST_DONE;
             }
-            goL = (__ballot(innode && nd.go == SWD_GO_LEFT) >> base) & SubVals<K>::MASK;
-            goR = (__ballot(innode && nd.go == SWD_GO_RIGHT) >> base) & SubVals<K>::MASK;
+            if (!__any(live)) break;
+            double mc = __longlong_as_double(0x7ff8000000000000ll), mom = 0.0, dl = 0.0;
+            int nt = 0;
+            if (live) {
+                R = swd_teamw_round(S, tg, perl, K, nxt);
+                nt = R.nt;
+                if (tl < nt) swd_teamw_trial(R, S, tl, &mc, &mom);
+            }
+            if (live && tl < nt && mc == mc) {                               // (NaN: a scan slot out of bounds)
+                const double wvno = mom / mc;
+                dl = (tg.iwave == 1) ? swd_dltar1(lay, S.mmax, S.llw, wvno, mom) : swd_dltar4(lay, S.mmax, S.llw, wvno, mom);
+            }
+            tc[tl] = mc;
+            dls[tl] = dl;
+            __syncthreads();
+            unsigned long long goL = 0, goR = 0;
+            {
+                // refinement round: lane j works out node j of the bisection tree (what the search does when it
+                // arrives there), the consuming loop then follows the decisions
+                const bool innode = live && R.nhalf > 0 && tl <= R.nhalf;
+                TeamwNode nd;
+                nd.go = SWD_GO_STOP; nd.out = SWD_OUT_CONTROL; nd.c1 = nd.d1 = nd.c2 = nd.d2 = nd.c3n = 0.0;
+                if (innode) {
+                    nd = swd_teamw_node(S, R, LdsSlots{dls, tc}, tl);
+                    nout[tl] = nd.out;
+                    ndc[tl] = nd.c1; ndc[K + tl] = nd.d1; ndc[2 * K + tl] = nd.c2; ndc[3 * K + tl] = nd.d2; ndc[4 * K + tl] = nd.c3n;
+                }
+                goL = (__ballot(innode && nd.go == SWD_GO_LEFT) >> base) & SubVals<K>::MASK;
+                goR = (__ballot(innode && nd.go == SWD_GO_RIGHT) >> base) & SubVals<K>::MASK;
+            }
+            __syncthreads();
+            if (live) {
+                SubVals<K> v{mc, mom, dl, nt, tl, base, tc, dls, ndc, nout, goL, goR};
+                (void)swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (live) {
-            SubVals<K> v{mc, mom, dl, nt, tl, base, tc, dls, ndc, nout, goL, goR};
-            (void)swd_teamw_consume(S, nv, lay, src, tg, perl, A.B, R, v);
-        }
-        __syncthreads();
     }
 }
 
