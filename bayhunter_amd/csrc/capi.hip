@@ -655,9 +655,13 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
             int w = l.width;
             while (w > 64 && bh::swd_team_lds_bytes(Lmax, w) > 160 * 1024) w /= 2;
             int team_resident = resident;
+#ifndef BH_NARROW_WAVES
+#define BH_NARROW_WAVES 3
+#endif
+            constexpr long BH_NARROW_WAVES_HOST = BH_NARROW_WAVES;     // waves per SIMD the narrow kernels are built for
             if (w < 64) {           // persistent waves of a narrow-team kernel that stay resident
                 long per_cu = (long)(160 * 1024 / bh::swd_team_lds_bytes(Lmax, w));
-                long waves = cus * (per_cu > 8 ? 8 : per_cu);
+                long waves = cus * (per_cu > 4 * BH_NARROW_WAVES_HOST ? 4 * BH_NARROW_WAVES_HOST : per_cu);
                 team_resident = (int)(waves > 0 ? waves : 1);
             }
             le = bh::launch_swd_team(A, w, team_resident, st);

@@ -689,12 +689,21 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
 {
     extern __shared__ double tlds[];
     constexpr int NL = SWD_T * W;
+    // The one-wave team evaluates ONE TRIAL PER LANE -- 64 slots a round, each lane the whole period equation of its
+    // trial (swd_dltar4 / swd_dltar1), no matrices in LDS -- like the narrow teams of swd_tpl_body, with the wave's
+    // uniform control code.  (Until round 4 it spread the layers of 64 / nlm trials over its lanes like the wider
+    // teams; -DBH_TEAM64_LAYERS.)
+#if defined(BH_TEAM64_LAYERS)
+    constexpr bool TPL = false;
+#else
+    constexpr bool TPL = W == 1;
+#endif
     const int lane = threadIdx.x, wl = lane & 63, wave = uni(lane >> 6);
     const bool ctl = W == 1 || wave == 0;
     const int t = blockIdx.y;
     if (!((A.tmask >> t) & 1u)) return;              // not a target of this launch (kernels.h)
     const SwdTargetDev tg = A.tg[t];
-    const int nm = A.Lmax > NL ? A.Lmax : NL;
+    const int nm = TPL ? 0 : (A.Lmax > NL ? A.Lmax : NL);                 // (no matrix slots: one trial per lane)
     double *mats = tlds, *dels = mats + swd_mat_off(nm), *perl = dels + SWD_TEAMW_NT, *nevt = perl + BH_NP;
     double *tcl = nevt + 24 * W, *toml = tcl + SWD_TEAMW_NT;
     float *res = (float *)(toml + SWD_TEAMW_NT);                 // [BH_NP] staged results
@@ -747,7 +756,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             fin = S.st == SWD_ST_DONE;
             BH_TP(0);
             if (!fin) {
-                if (first) cap = swd_teamw_cap(S.mmax - S.llw, W, tg.iwave);
+                if (first) cap = TPL ? (int)SWD_TEAMW_NT : swd_teamw_cap(S.mmax - S.llw, W, tg.iwave);
                 R = swd_teamw_round(S, tg, perl, cap, nxt);
                 nt = R.nt;
                 BH_TP(13);
@@ -768,7 +777,7 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
         const int nlm = S.mmax - S.llw;
         if (first) {          // slots per round, and which (trial, layer) this lane assembles
             first = false;
-            cap = swd_teamw_cap(nlm, W, tg.iwave);
+            cap = TPL ? (int)SWD_TEAMW_NT : swd_teamw_cap(nlm, W, tg.iwave);
 // (lanes of a wave hold the layers of few trials.  Layer-major -- a wave holding one or two layers for
             // many trials, so that it runs one branch of `var` instead of both -- was measured: 1 % faster on 15
             // layers x 512 lanes, 8 % slower on 5 layers x 64 lanes; same-box A/B, profiles/r03_ab_team.txt)
@@ -780,35 +789,46 @@ __device__ __forceinline__ void swd_teamw_body(const SwdArgs &A)
             mine = OneLay{lay.d(i0), lay.a(i0), lay.b(i0), lay.rho(i0)};
             half = OneLay{lay.d(ih), lay.a(ih), lay.b(ih), lay.rho(ih)};
         }
-        const int jq = 16 * wave + (wl >> 2);
-        if (cap > 1) {
-            if (ja < nt && nlm > 0) {
-                const double ac = tcl[ja];
-                if (ac == ac)                                           // (NaN: a scan slot out of bounds)
-                    swd_teamw_assemble_one(mine, tg.iwave, S, ra, ac, toml[ja], mats + swd_mat_off(lane));
+        if (TPL) {
+            double dl = 0.0;
+            if (wl < nt && mc == mc) {                                  // (NaN: a scan slot out of bounds)
+                const double wvno = mom / mc;
+                dl = (tg.iwave == 1) ? swd_dltar1(lay, S.mmax, S.llw, wvno, mom) : swd_dltar4(lay, S.mmax, S.llw, wvno, mom);
             }
+            dels[wl] = dl;
+            __syncthreads();
+            BH_TP(2);
         } else {
-            const double c0 = tcl[0], om0 = toml[0];
-            for (int r = lane; r < nlm; r += NL)
-                swd_teamw_assemble_one(lay, tg.iwave, S, r, c0, om0, mats + swd_mat_off(r));
-        }
-        const bool qvalid = jq < nt;
-        const double qc = tcl[qvalid ? jq : 0], qom = toml[qvalid ? jq : 0];
-        __syncthreads();
-        BH_TP(2);
-        if (tg.iwave == 2) {
-            // A wave chains 16 trials (one per quad) in the time it chains one: the trials fill waves 0, 1, ...
-            // and a wave without any skips the chain -- with eight waves on four SIMDs an idle wave walking
-            // through the chain (on trial 0, as an invalid quad does) took issue slots from the wave that
-            // shares its SIMD: 8 700 instead of 5 700 cycles per round on 15 layers (team512).
-            if (W == 1 || 16 * wave < nt) {
-                const double del = swd_teamw_chain_quad(lay, half, S, qc, qom, mats, (qvalid ? jq : 0) * nlm);
-                if (qvalid && (wl & 3) == 0) dels[jq] = del;
+            const int jq = 16 * wave + (wl >> 2);
+            if (cap > 1) {
+                if (ja < nt && nlm > 0) {
+                    const double ac = tcl[ja];
+                    if (ac == ac)                                           // (NaN: a scan slot out of bounds)
+                        swd_teamw_assemble_one(mine, tg.iwave, S, ra, ac, toml[ja], mats + swd_mat_off(lane));
+                }
+            } else {
+                const double c0 = tcl[0], om0 = toml[0];
+                for (int r = lane; r < nlm; r += NL)
+                    swd_teamw_assemble_one(lay, tg.iwave, S, r, c0, om0, mats + swd_mat_off(r));
             }
-        } else if (lane < nt) {
-            dels[lane] = swd_teamw_chain_one(lay, 1, S, mc, mom, mats, lane * nlm);
+            const bool qvalid = jq < nt;
+            const double qc = tcl[qvalid ? jq : 0], qom = toml[qvalid ? jq : 0];
+            __syncthreads();
+            BH_TP(2);
+            if (tg.iwave == 2) {
+                // A wave chains 16 trials (one per quad) in the time it chains one: the trials fill waves 0, 1, ...
+                // and a wave without any skips the chain -- with eight waves on four SIMDs an idle wave walking
+                // through the chain (on trial 0, as an invalid quad does) took issue slots from the wave that
+                // shares its SIMD: 8 700 instead of 5 700 cycles per round on 15 layers (team512).
+                if (W == 1 || 16 * wave < nt) {
+                    const double del = swd_teamw_chain_quad(lay, half, S, qc, qom, mats, (qvalid ? jq : 0) * nlm);
+                    if (qvalid && (wl & 3) == 0) dels[jq] = del;
+                }
+            } else if (lane < nt) {
+                dels[lane] = swd_teamw_chain_one(lay, 1, S, mc, mom, mats, lane * nlm);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         BH_TP(3);
         if (ctl) {
             // refinement round: lane j evaluates node j of the bisection tree (what the search does when
@@ -939,19 +959,29 @@ __device__ __forceinline__ void swd_tpl_body(const SwdArgs &A)
 // Three waves per SIMD: <= 168 VGPRs (the body needs ~140; without the bound the register allocator spreads out
 // to 189 and, with the 12.9 KB of LDS a 64-lane team takes, the registers would be what limits a CU to eight teams).
 #define BH_TEAMW_ATTR __attribute__((amdgpu_waves_per_eu(3)))
-__global__ __launch_bounds__(SWD_T) BH_TEAMW_ATTR void swd_team_kernel(SwdArgs A) { swd_teamw_body<1>(A); }
+#if defined(BH_TEAM64_LAYERS)
+#define BH_TEAM64_ATTR BH_TEAMW_ATTR
+#else
+#define BH_TEAM64_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#endif
+__global__ __launch_bounds__(SWD_T) BH_TEAM64_ATTR void swd_team_kernel(SwdArgs A) { swd_teamw_body<1>(A); }
 __global__ __launch_bounds__(2 * SWD_T) BH_TEAMW_ATTR void swd_team128_kernel(SwdArgs A) { swd_teamw_body<2>(A); }
 __global__ __launch_bounds__(4 * SWD_T) BH_TEAMW_ATTR void swd_team256_kernel(SwdArgs A) { swd_teamw_body<4>(A); }
 __global__ __launch_bounds__(8 * SWD_T) BH_TEAMW_ATTR void swd_team512_kernel(SwdArgs A) { swd_teamw_body<8>(A); }
 
 #if defined(BH_NARROW_LAYERS)
 #define BH_NARROW_BODY swd_team_body
+#define BH_NARROW_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #else
 #define BH_NARROW_BODY swd_tpl_body
+#ifndef BH_NARROW_WAVES
+#define BH_NARROW_WAVES 3
 #endif
-__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team32_kernel(SwdArgs A) { BH_NARROW_BODY<32>(A); }
-__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team16_kernel(SwdArgs A) { BH_NARROW_BODY<16>(A); }
-__global__ __launch_bounds__(SWD_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_team8_kernel(SwdArgs A) { BH_NARROW_BODY<8>(A); }
+#define BH_NARROW_ATTR __attribute__((amdgpu_waves_per_eu(BH_NARROW_WAVES)))
+#endif
+__global__ __launch_bounds__(SWD_T) BH_NARROW_ATTR void swd_team32_kernel(SwdArgs A) { BH_NARROW_BODY<32>(A); }
+__global__ __launch_bounds__(SWD_T) BH_NARROW_ATTR void swd_team16_kernel(SwdArgs A) { BH_NARROW_BODY<16>(A); }
+__global__ __launch_bounds__(SWD_T) BH_NARROW_ATTR void swd_team8_kernel(SwdArgs A) { BH_NARROW_BODY<8>(A); }
 
 // -------------------------------------------------------------------------------------------- RF
 // bit reversal (+ 1/sqrt(n)) and radix-2 butterflies of Mb buffers in LDS; all threads of the group
@@ -1107,7 +1137,11 @@ extern "C" int bh_debug_team_profile(unsigned long long *out, int reset)
 size_t swd_team_lds_bytes(int Lmax, int team)
 {
     if (team >= SWD_T) {           // wide teams: max(Lmax, lanes) matrix slots, dels, periods, layer stack
+#if defined(BH_TEAM64_LAYERS)
         const int nm = Lmax > team ? Lmax : team;
+#else
+        const int nm = team == SWD_T ? 0 : (Lmax > team ? Lmax : team);      // (the one-wave team keeps no matrices)
+#endif
         return ((size_t)swd_mat_off(nm) + 3 * SWD_TEAMW_NT + BH_NP + 24 * (team / SWD_T) + BH_NP / 2 + (4 * Lmax + 1) / 2) * sizeof(double);
     }
     const int nsub = SWD_T / team;

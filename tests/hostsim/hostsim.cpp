@@ -160,7 +160,7 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
     std::vector<double> cws(kmax > 0 ? kmax : 1), cbws(kmax > 0 ? kmax : 1);
     OneTask src{HostLay{d.data(), a.data(), b.data(), r.data()}, nlayer, 0, -1, cg, cws.data(), cbws.data()};
     const int NT = bh::SWD_TEAMW_NT;
-    std::vector<double> mats((size_t)bh::swd_mat_off(nlanes < 64 ? nlanes * nlayer : nlanes > nlayer ? nlanes : nlayer)), tc(NT), tom(NT), dl(NT);
+    std::vector<double> mats((size_t)bh::swd_mat_off(nlanes <= 64 ? nlanes * nlayer : nlanes > nlayer ? nlanes : nlayer)), tc(NT), tom(NT), dl(NT);
     bh::SwdState S;
     bh::swd_state_init(S);
     double nx[12], ny[12];
@@ -172,9 +172,9 @@ extern "C" int hs_surfdisp96_teamw(const float *thkm, const float *vpm, const fl
         bh::swd_driver(S, lay, src, tg, t, 1);
         if (S.st == bh::SWD_ST_DONE) break;
         const int nlm = S.mmax - S.llw;
-        // (the device's slots per round: a wide team's by its layers; a narrow team -- fewer than 64 lanes, one trial
-        // per lane, kernels.hip swd_tpl_body -- has one slot per lane)
-        const int cap = nlanes < 64 ? nlanes : bh::swd_teamw_cap(nlm, nlanes / 64, iwave);
+        // (the device's slots per round: a wide team's by its layers; a team of up to 64 lanes -- one trial per lane,
+        // kernels.hip swd_tpl_body and the one-wave team -- has one slot per lane)
+        const int cap = nlanes <= 64 ? nlanes : bh::swd_teamw_cap(nlm, nlanes / 64, iwave);
         const bh::TeamwRound R = bh::swd_teamw_round(S, tg, t, cap, nxt);
         const int nt = R.nt;
         if (nt < 1 || nt > NT || nt > (cap > 1 ? cap : 1)) return -100;      // layout invariants
