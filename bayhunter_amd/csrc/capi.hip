@@ -656,7 +656,7 @@ int bh_swd_batch_ordered(int B, int Lmax, int model_stride, const int *nlay, con
             while (w > 64 && bh::swd_team_lds_bytes(Lmax, w) > 160 * 1024) w /= 2;
             int team_resident = resident;
 #ifndef BH_NARROW_WAVES
-#define BH_NARROW_WAVES 3
+#define BH_NARROW_WAVES 2
 #endif
             constexpr long BH_NARROW_WAVES_HOST = BH_NARROW_WAVES;     // waves per SIMD the narrow kernels are built for
             if (w < 64) {           // persistent waves of a narrow-team kernel that stay resident

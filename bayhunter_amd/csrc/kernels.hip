@@ -975,7 +975,7 @@ __global__ __launch_bounds__(8 * SWD_T) BH_TEAMW_ATTR void swd_team512_kernel(Sw
 #else
 #define BH_NARROW_BODY swd_tpl_body
 #ifndef BH_NARROW_WAVES
-#define BH_NARROW_WAVES 3
+#define BH_NARROW_WAVES 2
 #endif
 #define BH_NARROW_ATTR __attribute__((amdgpu_waves_per_eu(BH_NARROW_WAVES)))
 #endif

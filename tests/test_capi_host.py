@@ -180,8 +180,8 @@ def test_form_plan_follows_the_measured_table():
         _lib.check(lib.bh_swd_plan_forms(B, L, len(specs), tg, 256, forms))
         return list(forms)
     cfg3 = [(2, 0, 40), (2, 1, 40), (1, 0, 40), (1, 1, 40)]
-    assert plan(8192, 10, cfg3) == [16] * 4 and plan(8192, 5, cfg3) == [8] * 4
-    assert plan(2048, 10, cfg3) == [16] * 4 and plan(16384, 10, cfg3) == [8] * 4 and plan(32768, 10, cfg3) == [0] * 4
+    assert plan(8192, 10, cfg3) == [8] * 4 and plan(8192, 5, cfg3) == [8] * 4
+    assert plan(2048, 10, cfg3) == [16] * 4 and plan(16384, 10, cfg3) == [0] * 4
     assert plan(64, 10, cfg3) == [512] * 4 and plan(524288, 10, cfg3) == [0] * 4
     assert plan(12288, 10, [(2, 0, 21)]) == [16] and plan(524288, 10, [(2, 0, 21)]) == [0]
     # a sampler's ragged batch (proposals of a tutorial pool: 2-14 layers, 4.8 on average): priced by its mean depth and

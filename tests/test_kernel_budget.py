@@ -21,20 +21,19 @@ def test_swd_and_rf_kernels_fit_one_simd_together():
     r = kernel_resources()
     assert set(r) >= {'swd_kernel', 'rf_kernel<false>', 'rf_kernel<true>', 'swd_team_kernel', 'swd_team8_kernel',
                       'swd_team512_kernel'}, sorted(r)
-    # nothing spills to memory -- except the narrow teams, built for three waves per SIMD since round 4: 168 VGPRs and
-    # 96-112 bytes of scratch per lane against 200 VGPRs and two waves (measured: cfg3 12.7 -> 11.6 ms, 16 384 x 4
-    # targets 23.5 -> 20.7 ms, single-target batches +-5 %; profiles/r04_ab_narrow_waves.txt)
-    narrow = ('swd_team8_kernel', 'swd_team16_kernel', 'swd_team32_kernel')
-    assert all(v['scratch'] == 0 for k, v in r.items() if k not in narrow), r
-    assert all(r[k]['scratch'] <= 128 for k in narrow), r
+    assert all(v['scratch'] == 0 for v in r.values()), r          # nothing spills to memory
     assert _alloc(r['swd_kernel']['vgpr']) <= 192 and _alloc(r['rf_kernel<false>']['vgpr']) <= 128, r
     assert 2 * _alloc(r['swd_kernel']['vgpr']) + _alloc(r['rf_kernel<false>']['vgpr']) <= 512
     # a multi-target call that is latency-bound on the lane kernel moves its heaviest target to 128-lane teams beside it
     # (capi.hip: plan_forms; BASELINE cfg3: 22.7 -> 17 ms): one lane-kernel wave and two team waves share a SIMD.
     # (Ten more registers in the wide teams -- a Neville table in register lanes, round 4 -- and cfg3 took 28.7 ms.)
     assert _alloc(r['swd_kernel']['vgpr']) + 2 * _alloc(r['swd_team128_kernel']['vgpr']) <= 512, r
-    # every team form keeps three waves per SIMD (the one-wave team four: 128 VGPRs)
+    # the narrow teams (8 .. 32 lanes per search, a lane's whole period equation like swd_kernel) keep two waves per SIMD
+    # -- built for three they take 168 VGPRs + 96-112 B of scratch: cfg3 12.7 -> 12.0 ms but cfg5 4.4 -> 5.5 ms, its 2 048
+    # waves no longer one full layer of the chip (profiles/r04_ab_narrow_waves.txt) --, the teams of 128 .. 512 lanes three,
+    # the one-wave team four (one trial per lane in 127 VGPRs)
     for k, v in r.items():
         if k.startswith('swd_team'):
-            assert _alloc(v['vgpr']) <= 168, (k, v)
+            narrow = k in ('swd_team8_kernel', 'swd_team16_kernel', 'swd_team32_kernel')
+            assert _alloc(v['vgpr']) <= (256 if narrow else 168), (k, v)
     assert _alloc(r['swd_team_kernel']['vgpr']) <= 128, r
