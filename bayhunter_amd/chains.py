@@ -38,6 +38,7 @@ DEFAULT_INITPARAMS = dict(nchains=3, iter_burnin=2048 * 2, iter_main=2048, propd
 
 
 LOOKAHEAD_MAX = 64        # BH_CHAIN_MAX_LOOKAHEAD
+LOOKAHEAD_DEFAULT_MAX = 32    # (5 chains: 32 proposals each -- 130 models a call -- 2.36 s, 57 of them 2.84 s: profiles/r04_lookahead_tiny.txt)
 LOOKAHEAD_SCALE = 128.    # default look-ahead = LOOKAHEAD_SCALE / sqrt(chains per group) (profiles/r04_lookahead_sweep.txt)
 
 
@@ -196,7 +197,7 @@ class ChainPool(object):
                  the ones before and advances by as many iterations as the likelihoods confirm -- the same
                  samples in fewer, larger device calls.  Default: LOOKAHEAD_SCALE / sqrt(chains per group)
                  when the evaluator is the GPU's (small pools are bound by the latency of a call more than by
-                 its size: 57 proposals per chain for 5 chains, 16 for 64, 4 for 1 024, 1 from 16 384 per
+                 its size: 32 proposals per chain up to 16 chains, 16 for 64, 4 for 1 024, 1 from 16 384 per
                  group), 1 for any other evaluator.
     shard        (rank, world): this process runs only its contiguous block of the nchains chains
                  (distributed.shard_range), one process per GPU.  Seeds are drawn for ALL chains
@@ -273,7 +274,7 @@ class ChainPool(object):
         bounds = [(g * self.nchains) // groups for g in range(groups + 1)]
         if lookahead is None:
             per_group = max(1, self.nchains // groups)
-            lookahead = max(1, min(LOOKAHEAD_MAX, int(LOOKAHEAD_SCALE / np.sqrt(per_group)))) \
+            lookahead = max(1, min(LOOKAHEAD_DEFAULT_MAX, int(LOOKAHEAD_SCALE / np.sqrt(per_group)))) \
                 if isinstance(evaluator, GpuEvaluator) else 1
         self.lookahead = int(lookahead)
         if not 1 <= self.lookahead <= LOOKAHEAD_MAX:

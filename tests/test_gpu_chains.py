@@ -78,7 +78,7 @@ def test_gpu_pool_lookahead_same_chains_in_fewer_calls():
     seeds = list(range(40, 52))
     one = make_pool(None, DATA, case, seeds=seeds, evaluator=gpu_evaluator, lookahead=1).run()
     auto = make_pool(None, DATA, case, seeds=seeds, evaluator=gpu_evaluator).run()
-    assert one.lookahead == 1 and auto.lookahead == 36          # 128 / sqrt(12 chains)
+    assert one.lookahead == 1 and auto.lookahead == 32          # min(32, 128 / sqrt(12 chains))
     for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
         assert np.array_equal(getattr(one, k), getattr(auto, k), equal_nan=True), k
     for a, b in zip(one.counters(), auto.counters()):

@@ -25,6 +25,9 @@ def main():
     burnin = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
     main_it = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
     lookahead = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    if 'BH_SWD_KERNEL' in os.environ:                      # pin a kernel form (experiments)
+        from bayhunter_amd import _lib as _l
+        _l.set_swd_kernel(os.environ['BH_SWD_KERNEL'])
     d = os.path.join(ROOT, 'tests', 'golden', 'tutorial_observed')
     sw, rf = np.loadtxt(os.path.join(d, 'st3_rdispph.dat')), np.loadtxt(os.path.join(d, 'st3_prf.dat'))
     joint = T.JointTarget([T.RayleighDispersionPhase(sw[:, 0], sw[:, 1]), T.PReceiverFunction(rf[:, 0], rf[:, 1])])
