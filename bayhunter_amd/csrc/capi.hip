@@ -399,6 +399,11 @@ void plan_forms(int B, int Lmax, int ntargets, const bh_swd_target *targets, lon
     const int regime_thr = (mean_layers > 0.0 && mean_layers < (double)Lmax) ? regime_of(mean_layers) : regime;
     if (load < 1) load = 1;
     const long searches = (long)B * ntargets;
+    // (calls of fewer than ~3 000 searches do not feel the other group's: with the load priced in, pools of 512 and
+    // 1 024 chains -- 2 000-2 300 proposals a call -- were put on 32-lane teams where the one-wave team is 10 % faster,
+    // a 1 024-chain inversion 6.1 instead of 5.4 s; from 2 048 chains on -- 3 500 proposals a call -- pricing it is
+    // worth 2-20 %: profiles/r04_plan_load.txt)
+    if (searches < 3000) load = 1;
     const double scale = 256.0 / (double)cus;                  // the table's chip has 256 CUs
     auto allowed = [&](int k) {
         if (bh::kFormWidth[k] == 0) return true;
