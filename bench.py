@@ -146,7 +146,8 @@ def measured_traffic(kernel, workload, B, live_ms, lib_hash, tol=0.05):
     passes (profiles/*_traffic.json: FETCH_SIZE doubled + WRITE_SIZE, separate --pmc runs) taken at
     this configuration -- bench.py itself cannot collect PMC counters.  The record is only used when
     it belongs to THIS code: its `lib_src_hash` must be the hash compiled into the loaded library and
-    the kernel time measured live must agree with the record's rocprof time within 5 %.  Returns
+    the kernel time measured live must agree with the record's rocprof time within `tol` (5 % for the lane kernel,
+    10 % for a team kernel, 15 % for a call that runs its targets on several forms).  Returns
     (record or None, note)."""
     import glob
     best, name = None, None
@@ -588,7 +589,10 @@ def rooflines(r, lib_hash):
     mixed = len(set(r['forms'].values())) > 1
     swd = one(kernel_symbol(r['form']), r['ms_swd'], flop_swd, bytes_swd,
               {"n_dltar_per_eval": counts, "form": form_name(r['form'], r['forms']),
-               "flop_model": "N_dltar x (L-1) x 190 (Rayleigh) / 30 (Love), FMA = 2"}, tol=0.15 if mixed else 0.05)
+               "flop_model": "N_dltar x (L-1) x 190 (Rayleigh) / 30 (Love), FMA = 2"},
+              # (a team kernel's time varies by up to 7 % from launch to launch under rocprofv3 -- cfg5: 4.19-5.6 ms over
+              # 13 launches, which waves share a SIMD -- the lane kernel's by 1 %)
+              tol=0.15 if mixed else 0.10 if r['form'] else 0.05)
     rf = one('rf_kernel', r['ms_rf'], flop_rf, bytes_rf,
              {"frequencies_computed": r['nact'], "frequencies_total": RF_NSAMP // 2 + 1,
               "flop_model": "nact x (L-1) x 500 + L x 300 + nact x 60 + 5 nsamp log2 nsamp (SURVEY 8d with "
