@@ -54,8 +54,10 @@ def test_swd_team_replay_bitexact(oracle, hostsim, L, srt):
 def test_swd_wide_team_replay_bitexact(oracle, hostsim, L, srt):
     """Wide teams (swd_teamw_*: slot layout, bisection candidates, speculation across the end of a root
     search, value-matched consumption with run fast-forward, Neville tables in memory): same values,
-    err flags and number of CONSUMED evaluations as the reference for 64/128/256 lanes; the replay
-    itself checks the plan's invariants.  Rounds per period roughly halve against the round-1 scheme."""
+    err flags and number of CONSUMED evaluations as the reference for 64/128/256 lanes -- and for the plan with 8, 16,
+    32 and 64 slots per round, which is what the teams of one trial per lane run (kernels.hip: swd_tpl_body and the
+    one-wave team; nlanes <= 64 in the replay); the replay itself checks the plan's invariants.  Rounds per period
+    roughly halve against the round-1 scheme."""
     kw = dict(zmax=300.0, thickmin=0.05) if L > 40 else {}
     H, VP, VS, RHO, nl = draw_models(5, L, seed=1700 + L + int(srt), sorted_vs=srt, **kw)
     per = np.linspace(1, 41, 21)
@@ -65,7 +67,7 @@ def test_swd_wide_team_replay_bitexact(oracle, hostsim, L, srt):
             for b in range(5):
                 n = nl[b]
                 a, e1, n1 = oracle.swd(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], per, iw, ig, mode, fl, count=True)
-                for nlanes in (64, 128, 256):
+                for nlanes in (8, 16, 32, 64, 128, 256):
                     r, e2, n2, nspec, nrounds = hostsim.swd_team(H[b, :n], VP[b, :n], VS[b, :n], RHO[b, :n], per,
                                                                   iw, ig, mode, fl, nlanes, wide=True)
                     assert e2 >= 0, 'plan invariant %d violated' % e2
