@@ -379,6 +379,59 @@ def test_lookahead_chain_is_the_golden_chain(oracle, golden_chains):
         assert iters == len(seeds) * (case['burnin'] + case['main']) and calls < 0.6 * (case['burnin'] + case['main'])
 
 
+def test_lookahead_changed_mid_run_and_short_runs(lib):
+    """The look-ahead may be changed whenever no results are outstanding, a tree never reaches past the last
+    iteration (2 iterations with 16 proposals per call), and a chain that overflows its storage inside a tree stops
+    the pool like it does without one."""
+    from bayhunter_amd import _lib
+    from chain_scenario import joint_target
+    from bayhunter_amd.chains import ChainPool
+    case = CASES['constrained']
+
+    def toy(packed, nlay, noise):
+        vs, h = packed[:, 2, :], packed[:, 0, :]
+        d = vs[:, 0] - 3.1 + 0.01 * nlay + 0.002 * h.sum(axis=1)
+        return -40. * d * d - 3. * noise[:, 3], np.stack([np.abs(d), np.abs(d), 2 * np.abs(d)], axis=1)
+
+    def pool(burnin, main, lookahead, n=9, **kw):
+        ip = dict(case['initparams'], iter_burnin=burnin, iter_main=main, acceptance=(40, 100))
+        return ChainPool(joint_target(DATA), initparams=ip, modelpriors=case['priors'], seeds=np.arange(n) + 5, evaluator=toy,
+                         groups=1, lookahead=lookahead, **kw)
+    ref = pool(260, 140, 1).run()
+    # 16 rows per chain are staged; the look-ahead switches 16 -> 3 -> 1 -> 9 while the pool runs
+    p = pool(260, 140, 16)
+    g = p.groups[0]
+    p._launch(g)
+    step = 0
+    while True:
+        p._land(g)
+        if g.done():
+            break
+        step += 1
+        if step in (5, 11, 40):
+            assert lib.bh_chains_set_lookahead(g.handle, {5: 3, 11: 1, 40: 9}[step]) == _lib.BH_OK
+        g.propose()                                       # ... and refused while results are due
+        assert lib.bh_chains_set_lookahead(g.handle, 2) == _lib.BH_ERR_ARG
+        n = g.count
+        logL, mis = toy(g.packed[:n], g.nlay[:n], g.noise[:n])
+        g.accept(np.ascontiguousarray(logL), mis)
+        if g.done():
+            break
+        p._launch(g)
+    for k in ('models', 'likes', 'misfits', 'noise', 'vpvs', 'iter'):
+        assert np.array_equal(getattr(p, k), getattr(ref, k), equal_nan=True), k
+    for a, b in zip(p.counters(), ref.counters()):
+        assert np.array_equal(a, b)
+    # two iterations in all: the tree stops at the last one
+    short1, short16 = pool(1, 1, 1, nmodels=3).run(), pool(1, 1, 16, nmodels=3).run()
+    assert short16.advance()[1] == short1.advance()[1] == 9 * 2 and short16.advance()[0] <= 2
+    for k in ('models', 'likes', 'iter'):
+        assert np.array_equal(getattr(short1, k), getattr(short16, k), equal_nan=True), k
+    # storage for three rows per chain: a chain overflows inside a tree
+    with pytest.raises(_lib.BayHunterAmdError, match='storage'):
+        pool(40, 20, 8, nmodels=3).run()
+
+
 def test_move_and_acceptance_queries(lib):
     """bh_chains_moves / bh_chains_accepted: per model of the last batch, which move produced it and
     whether it became the chain's current model; consistent with the stored samples."""
