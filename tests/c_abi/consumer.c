@@ -64,6 +64,34 @@ int main(int argc, char **argv)
         printf("chains ok: %d rounds, iteration %ld, accepted %ld %ld %ld %ld\n", it, bh_chains_iteration(pool),
                nacc[0], nacc[1], nacc[2], nacc[3]);
         bh_chains_destroy(pool);
+        {   /* the same chains with a look-ahead of LA proposals per chain and call: staging arrays of bh_chains_rows()
+             * rows, fewer rounds, the same accepted models */
+            enum { LA = 6, NR = NC * LA };
+            static float models2[NC * NM * 2 * 6], misfits2[NC * NM * 2], likes2[NC * NM], noise2[NC * NM * 2], vpvs2[NC * NM];
+            static double iter2[NC * NM], packed2[NR * 4 * LMAX], pnoise2[NR * 2], logL2[NR], mis2[NR * 2];
+            int nlay2[NR], chain2[NR], it2 = 0;
+            long nacc2[NC], calls = 0, iters = 0, rows = 0;
+            st.models = models2; st.misfits = misfits2; st.likes = likes2; st.noise = noise2; st.vpvs = vpvs2; st.iter = iter2;
+            if (bh_chains_create(&cfg, NC, seeds, &st, &pool) != BH_OK) return 9;
+            if (bh_chains_set_lookahead(pool, LA) != BH_OK || bh_chains_rows(pool) != NR || bh_chains_lookahead(pool) != LA) return 10;
+            while (!bh_chains_done(pool)) {
+                if (bh_chains_propose(pool, LMAX, packed2, nlay2, pnoise2, chain2, &count) != BH_OK || count > NR) return 11;
+                for (i = 0; i < count; i++) {
+                    double d = packed2[i * 4 * LMAX + 2 * LMAX] - 3.5;
+                    logL2[i] = -50. * d * d; mis2[2 * i] = mis2[2 * i + 1] = d < 0 ? -d : d;
+                }
+                if (bh_chains_accept(pool, logL2, mis2) != BH_OK) { printf("accept: %s\n", bh_last_error()); return 12; }
+                it2++;
+            }
+            if (bh_chains_counters(pool, nacc2, NULL, NULL, NULL) != BH_OK || bh_chains_advance(pool, &calls, &iters, &rows) != BH_OK) return 13;
+            if (memcmp(nacc, nacc2, sizeof(nacc)) || memcmp(likes, likes2, sizeof(likes)) || memcmp(models, models2, sizeof(models)) ||
+                memcmp(iter, iter2, sizeof(iter)) || iters != NC * 60 || calls != it2 - 1 || it2 >= it) {
+                printf("look-ahead changed the chains (%d rounds, %ld iterations)\n", it2, iters);
+                return 14;
+            }
+            printf("look-ahead ok: %d rounds instead of %d, %ld rows\n", it2, it, rows);
+            bh_chains_destroy(pool);
+        }
     }
     if (argc > 1 && strcmp(argv[1], "run") == 0) {
         /* tutorial model st3 (tutorial/create_testdata.py:13-17), vp = 1.73 vs, rho = .77 + .32 vp */

@@ -28,6 +28,7 @@ def test_header_is_c99_and_links(lib):
     assert 'bayhunter_amd' in r.stdout and 'arg check ok' in r.stdout and 'literal names ok' in r.stdout
     assert 'surfdisp96_ failed' in r.stderr          # the library says why on stderr
     assert 'chains ok: 61 rounds, iteration 30' in r.stdout          # initial models + 60 iterations
+    assert 'look-ahead ok:' in r.stdout                              # the same chains, six proposals per chain and call
 
 
 @pytest.mark.gpu
