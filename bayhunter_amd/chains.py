@@ -38,6 +38,8 @@ DEFAULT_INITPARAMS = dict(nchains=3, iter_burnin=2048 * 2, iter_main=2048, propd
 
 
 LOOKAHEAD_MAX = 64        # BH_CHAIN_MAX_LOOKAHEAD
+GROUPS_MIN_CHAINS = 32        # two chain groups (one batch on the device while the host works on the other) from here on:
+                              # +11 ... +20 % from 32 to 1 024 chains, nothing below (profiles/r04_chain_groups.txt)
 LOOKAHEAD_DEFAULT_MAX = 32    # (5 chains: 32 proposals each -- 130 models a call -- 2.36 s, 57 of them 2.84 s: profiles/r04_lookahead_tiny.txt)
 LOOKAHEAD_SCALE = 128.    # default look-ahead = LOOKAHEAD_SCALE / sqrt(chains per group) (profiles/r04_lookahead_sweep.txt)
 
@@ -187,7 +189,7 @@ class ChainPool(object):
     evaluator    object with buffers/submit/collect (default GpuEvaluator) or a plain function
                  (packed[B,4,Lmax], nlay[B], noise[B,2*ntargets]) -> (logL[B], misfits[B,ntargets+1])
     groups       number of chain groups alternating between host and GPU (default 2 when the pool
-                 has at least 512 chains, else 1)
+                 has at least 32 chains, else 1)
     nmodels      rows of sample storage per chain.  Default: the reference's
                  int(iterations * max(acceptance) / 100) (src/mcmcOptimizer.py:87-89) -- a chain that
                  accepts more than that overflows (IndexError there, an error from bh_chains_accept
@@ -269,7 +271,7 @@ class ChainPool(object):
             evaluator = _CallEvaluator(evaluator)
         self.evaluator = evaluator
         if groups is None:
-            groups = 2 if self.nchains >= 512 else 1
+            groups = 2 if self.nchains >= GROUPS_MIN_CHAINS else 1
         groups = max(1, min(int(groups), self.nchains))
         bounds = [(g * self.nchains) // groups for g in range(groups + 1)]
         if lookahead is None:
