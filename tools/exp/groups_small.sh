@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 export CHAIN_BENCH_ITERS=1200
 for n in ${POOLS:-64 128 256 384 512 1024}; do
-  for g in 1 2; do
+  for g in ${GROUPS_LIST:-1 2}; do
     echo -n "chains $n groups $g  "
     CHAIN_BENCH_GROUPS=$g timeout -k 10 200 python tools/chain_bench.py $n 2>/dev/null | python -c "
 import json,sys
