@@ -41,7 +41,20 @@ LOOKAHEAD_MAX = 64        # BH_CHAIN_MAX_LOOKAHEAD
 GROUPS_MIN_CHAINS = 32        # two chain groups (one batch on the device while the host works on the other) from here on:
                               # +11 ... +20 % from 32 to 1 024 chains, nothing below (profiles/r04_chain_groups.txt)
 LOOKAHEAD_DEFAULT_MAX = 32    # (5 chains: 32 proposals each -- 130 models a call -- 2.36 s, 57 of them 2.84 s: profiles/r04_lookahead_tiny.txt)
+LOOKAHEAD_ROWS, LOOKAHEAD_MID_MAX = 6500, 8
 LOOKAHEAD_SCALE = 128.    # default look-ahead = LOOKAHEAD_SCALE / sqrt(chains per group) (profiles/r04_lookahead_sweep.txt)
+
+
+def default_lookahead(per_group):
+    """Proposals per chain and device call for a group of `per_group` chains on the GPU.  Small groups are bound by the
+    latency of a call: LOOKAHEAD_SCALE / sqrt(chains), at most LOOKAHEAD_DEFAULT_MAX.  From a few hundred chains on the
+    narrow team kernels are at their best with LOOKAHEAD_ROWS models a call: that many rows,
+    at most LOOKAHEAD_MID_MAX proposals per chain; from ~8 000 chains per group a call is bound by throughput: 1.
+    (profiles/r04_lookahead_sweep.txt, r04_lookahead_groups.txt: measured best at 32 / 128 / 512 / 1 024 / 2 048 /
+    8 192 chains per group: 16-22 / 5-11 / 8 / 8 / 4 / 1.)"""
+    if per_group <= 256:
+        return max(1, min(LOOKAHEAD_DEFAULT_MAX, int(LOOKAHEAD_SCALE / np.sqrt(per_group))))
+    return max(1, min(LOOKAHEAD_MID_MAX, -(-LOOKAHEAD_ROWS // per_group)))
 
 
 def _is_number(x):
@@ -197,10 +210,10 @@ class ChainPool(object):
     lookahead    proposals per chain and device call (1 .. 64; bh_chains_set_lookahead): with more than one, a
                  chain also hands in the proposals of its following iterations for the likeliest outcomes of
                  the ones before and advances by as many iterations as the likelihoods confirm -- the same
-                 samples in fewer, larger device calls.  Default: LOOKAHEAD_SCALE / sqrt(chains per group)
+                 samples in fewer, larger device calls.  Default: default_lookahead(chains per group)
                  when the evaluator is the GPU's (small pools are bound by the latency of a call more than by
-                 its size: 32 proposals per chain up to 16 chains, 16 for 64, 4 for 1 024, 1 from 16 384 per
-                 group), 1 for any other evaluator.
+                 its size: 32 proposals per chain up to 16 chains, 22 for 64, 8 for 1 024, 4 for 4 096, 1 from
+                 16 384 chains on), 1 for any other evaluator.
     shard        (rank, world): this process runs only its contiguous block of the nchains chains
                  (distributed.shard_range), one process per GPU.  Seeds are drawn for ALL chains
                  first, so chain c is the same chain whatever the number of ranks; chains never
@@ -276,8 +289,7 @@ class ChainPool(object):
         bounds = [(g * self.nchains) // groups for g in range(groups + 1)]
         if lookahead is None:
             per_group = max(1, self.nchains // groups)
-            lookahead = max(1, min(LOOKAHEAD_DEFAULT_MAX, int(LOOKAHEAD_SCALE / np.sqrt(per_group)))) \
-                if isinstance(evaluator, GpuEvaluator) else 1
+            lookahead = default_lookahead(per_group) if isinstance(evaluator, GpuEvaluator) else 1
         self.lookahead = int(lookahead)
         if not 1 <= self.lookahead <= LOOKAHEAD_MAX:
             raise ValueError("lookahead: 1 .. %d proposals per chain and call" % LOOKAHEAD_MAX)
