@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-4 experiment: the switch BH_NARROW_GX_DIV it sets lived in kernels.hip for that measurement only and is not in the tree)
 cd "$(dirname "$0")/../.."
 for v in 1 2 3 4; do
   export BH_NARROW_GX_DIV=$v

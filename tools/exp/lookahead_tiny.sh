@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-4 experiment: the switch BH_GROUPS it sets lived in tools/tutorial_inversion.py for that measurement only and is not in the tree)
 # GPU box: the reference's 5-chain tutorial run against look-ahead and chain groups
 set -e
 cd "$(dirname "$0")/../.."

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-4 experiment: the switch BH_PLAN_LOAD it sets lived in capi.hip for that measurement only and is not in the tree)
 cd "$(dirname "$0")/../.."
 for v in 2 1; do
   export BH_PLAN_LOAD=$v

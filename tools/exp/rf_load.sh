@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-4 experiment: the switch BH_EVAL_LOAD_RF it sets lived in evalplan.hip for that measurement only and is not in the tree)
 cd "$(dirname "$0")/../.."
 for v in 1 2 3; do
   export BH_EVAL_LOAD_RF=$v
